@@ -1,0 +1,152 @@
+"""ctypes binding of libbtrblocks_amd.so (the C ABI declared in include/btrblocks_amd.h).
+
+The library is the product: HIP decode kernels for gfx950 plus the CPU compressor. There is no
+Python or CPU decode path here; every decode call goes through the shared library and fails
+loudly when it (or a GPU) is missing.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libbtrblocks_amd.so")
+
+BTR_OK = 0
+STATUS_NAMES = {
+    0: "BTR_OK",
+    1: "BTR_ERR_INVALID_ARGUMENT",
+    2: "BTR_ERR_CORRUPT",
+    3: "BTR_ERR_UNSUPPORTED",
+    4: "BTR_ERR_BUFFER_TOO_SMALL",
+    5: "BTR_ERR_DEVICE",
+    6: "BTR_ERR_MISALIGNED",
+    7: "BTR_ERR_OUT_OF_MEMORY",
+}
+
+COLUMN_INTEGER, COLUMN_DOUBLE, COLUMN_STRING = 0, 1, 2
+
+
+class BtrError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__(f"{STATUS_NAMES.get(status, status)}: {message}")
+        self.status = status
+
+
+class ChunkInfo(C.Structure):
+    _fields_ = [
+        ("tuple_count", C.c_uint32),
+        ("column_type", C.c_uint8),
+        ("scheme", C.c_uint8),
+        ("nullmap_type", C.c_uint8),
+        ("reserved", C.c_uint8),
+        ("decoded_bytes", C.c_uint64),
+    ]
+
+
+class CompressOptions(C.Structure):
+    _fields_ = [
+        ("max_cascade_depth", C.c_uint8),
+        ("enable_for", C.c_uint8),
+        ("reserved", C.c_uint8 * 6),
+    ]
+
+
+class ColumnInput(C.Structure):
+    _fields_ = [
+        ("column_type", C.c_uint8),
+        ("values", C.c_void_p),
+        ("nullmap", C.c_void_p),
+        ("scheme_spec", C.c_char_p),
+    ]
+
+
+class ChunkDesc(C.Structure):
+    _fields_ = [
+        ("host_src", C.c_void_p),
+        ("dev_src", C.c_void_p),
+        ("src_bytes", C.c_size_t),
+        ("dev_dst", C.c_void_p),
+        ("dst_bytes", C.c_size_t),
+        ("dev_nullmap_dst", C.c_void_p),
+    ]
+
+
+class PlanStats(C.Structure):
+    _fields_ = [
+        ("chunks", C.c_uint64),
+        ("tuples", C.c_uint64),
+        ("decoded_bytes", C.c_uint64),
+        ("nullmap_bytes", C.c_uint64),
+        ("needed_bytes", C.c_uint64),
+        ("stored_bytes", C.c_uint64),
+        ("scratch_bytes", C.c_uint64),
+        ("max_lds_bytes", C.c_uint32),
+        ("max_depth", C.c_uint32),
+    ]
+
+
+# Every symbol include/btrblocks_amd.h declares: name -> (restype, argtypes)
+_P = C.c_void_p
+SIGNATURES = {
+    "btr_last_error": (C.c_char_p, []),
+    "btr_version": (C.c_char_p, []),
+    "btr_chunk_inspect": (C.c_int, [_P, C.c_size_t, C.POINTER(ChunkInfo)]),
+    "btr_chunk_describe": (C.c_int, [_P, C.c_size_t, C.c_char_p, C.c_size_t]),
+    "btr_part_chunk_count": (C.c_int, [_P, C.c_size_t, C.POINTER(C.c_uint32)]),
+    "btr_part_chunk": (C.c_int, [_P, C.c_size_t, C.c_uint32, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    "btr_datablock_inspect": (C.c_int, [_P, C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "btr_datablock_column": (C.c_int, [_P, C.c_size_t, C.c_uint32, C.POINTER(ChunkInfo)]),
+    "btr_compress_bound": (C.c_size_t, [C.c_uint8, C.c_uint32]),
+    "btr_compress_chunk": (C.c_int, [C.c_uint8, _P, _P, C.c_uint32, C.c_char_p, C.POINTER(CompressOptions), _P,
+                                     C.c_size_t, C.POINTER(C.c_size_t)]),
+    "btr_compress_datablock": (C.c_int, [C.POINTER(ColumnInput), C.c_uint32, C.c_uint32,
+                                         C.POINTER(CompressOptions), _P, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "btr_compress_column": (C.c_int, [C.c_uint8, _P, _P, C.c_uint64, C.c_uint32, C.c_char_p,
+                                      C.POINTER(CompressOptions), C.c_int, _P, C.c_size_t,
+                                      C.POINTER(C.c_size_t)]),
+    "btr_compress_column_bound": (C.c_size_t, [C.c_uint8, C.c_uint64, C.c_uint32]),
+    "btr_gpu_ctx_create": (C.c_int, [C.c_int, C.POINTER(_P)]),
+    "btr_gpu_ctx_destroy": (None, [_P]),
+    "btr_gpu_plan_create": (C.c_int, [_P, C.POINTER(ChunkDesc), C.c_size_t, C.POINTER(_P)]),
+    "btr_gpu_plan_create_datablock": (C.c_int, [_P, _P, _P, C.c_size_t, C.POINTER(_P), C.POINTER(_P),
+                                                C.c_uint32, C.POINTER(_P)]),
+    "btr_gpu_plan_destroy": (None, [_P]),
+    "btr_gpu_plan_stats": (C.c_int, [_P, C.POINTER(PlanStats)]),
+    "btr_gpu_decode": (C.c_int, [_P, _P, _P]),
+    "btr_gpu_plan_check": (C.c_int, [_P, _P, _P, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]),
+    "btr_gpu_decode_chunk_host": (C.c_int, [_P, _P, C.c_size_t, _P, C.c_size_t, _P]),
+    "btr_gpu_malloc": (C.c_int, [_P, C.c_size_t, C.POINTER(_P)]),
+    "btr_gpu_free": (C.c_int, [_P, _P]),
+    "btr_gpu_upload": (C.c_int, [_P, _P, _P, C.c_size_t]),
+    "btr_gpu_download": (C.c_int, [_P, _P, _P, C.c_size_t]),
+    "btr_gpu_synchronize": (C.c_int, [_P, _P]),
+}
+
+_lib = None
+
+
+def load():
+    """Loads the shared library once. torch (when importable) is imported first so that both share
+    one HIP runtime and device pointers/streams are interchangeable."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -m btrblocks_amd.build` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback for decoding.")
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(status):
+    if status != BTR_OK:
+        raise BtrError(status, load().btr_last_error().decode("utf-8", "replace"))

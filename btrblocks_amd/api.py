@@ -1,0 +1,244 @@
+"""numpy / torch level wrappers over the C ABI.
+
+Host-side helpers (inspection, CPU compression) work on numpy arrays. GPU decode works on device
+buffers; torch is used only to own device memory and to name the current HIP stream.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _native as N
+
+_DTYPE = {N.COLUMN_INTEGER: np.int32, N.COLUMN_DOUBLE: np.float64}
+
+
+def _as_u8(buf):
+    a = np.frombuffer(buf, dtype=np.uint8) if not isinstance(buf, np.ndarray) else buf
+    if a.dtype != np.uint8:
+        a = a.view(np.uint8)
+    return np.ascontiguousarray(a)
+
+
+def _column_type(values):
+    if values.dtype == np.int32:
+        return N.COLUMN_INTEGER
+    if values.dtype == np.float64:
+        return N.COLUMN_DOUBLE
+    raise TypeError("columns must be int32 or float64 numpy arrays")
+
+
+def _options(max_cascade_depth=0, enable_for=False):
+    o = N.CompressOptions()
+    o.max_cascade_depth = max_cascade_depth
+    o.enable_for = 1 if enable_for else 0
+    return o
+
+
+def _nullmap_ptr(nullmap, n):
+    if nullmap is None:
+        return None, None
+    nm = np.ascontiguousarray(nullmap, dtype=np.uint8)
+    if nm.shape != (n,):
+        raise ValueError("nullmap must hold one byte per row")
+    return nm, nm.ctypes.data
+
+
+# ---------------------------------------------------------------------------------------------
+# inspection
+# ---------------------------------------------------------------------------------------------
+def chunk_info(chunk):
+    lib = N.load()
+    a = _as_u8(chunk)
+    info = N.ChunkInfo()
+    N.check(lib.btr_chunk_inspect(a.ctypes.data, a.size, C.byref(info)))
+    return info
+
+
+def describe(chunk):
+    """Scheme tree of a chunk as text, e.g. 'RLE(DICT(BP),BP)' (BtrReader::getSchemeDescription)."""
+    lib = N.load()
+    a = _as_u8(chunk)
+    out = C.create_string_buffer(1024)
+    N.check(lib.btr_chunk_describe(a.ctypes.data, a.size, out, len(out)))
+    return out.value.decode()
+
+
+def part_chunks(part):
+    """[(offset, length)] of the chunks of a column part image."""
+    lib = N.load()
+    a = _as_u8(part)
+    n = C.c_uint32()
+    N.check(lib.btr_part_chunk_count(a.ctypes.data, a.size, C.byref(n)))
+    out = []
+    off, ln = C.c_size_t(), C.c_size_t()
+    for i in range(n.value):
+        N.check(lib.btr_part_chunk(a.ctypes.data, a.size, i, C.byref(off), C.byref(ln)))
+        out.append((off.value, ln.value))
+    return out
+
+
+def datablock_columns(block):
+    lib = N.load()
+    a = _as_u8(block)
+    n, cols = C.c_uint32(), C.c_uint32()
+    N.check(lib.btr_datablock_inspect(a.ctypes.data, a.size, C.byref(n), C.byref(cols)))
+    infos = []
+    for c in range(cols.value):
+        info = N.ChunkInfo()
+        N.check(lib.btr_datablock_column(a.ctypes.data, a.size, c, C.byref(info)))
+        infos.append(info)
+    return n.value, infos
+
+
+# ---------------------------------------------------------------------------------------------
+# compression (CPU)
+# ---------------------------------------------------------------------------------------------
+def compress_chunk(values, nullmap=None, scheme="auto", max_cascade_depth=0, enable_for=False):
+    """One ColumnChunkMeta chunk as a uint8 array (Datablock::compress(const InputChunk&))."""
+    lib = N.load()
+    values = np.ascontiguousarray(values)
+    ctype = _column_type(values)
+    n = values.size
+    nm, nm_ptr = _nullmap_ptr(nullmap, n)
+    cap = lib.btr_compress_bound(ctype, n)
+    out = np.empty(cap, dtype=np.uint8)
+    got = C.c_size_t()
+    opt = _options(max_cascade_depth, enable_for)
+    N.check(lib.btr_compress_chunk(ctype, values.ctypes.data, nm_ptr, n, scheme.encode(), C.byref(opt),
+                                   out.ctypes.data, cap, C.byref(got)))
+    return out[:got.value].copy()
+
+
+def compress_column(values, nullmap=None, scheme="auto", block_rows=65536, threads=0,
+                    max_cascade_depth=0, enable_for=False):
+    """Column part image holding every 64k-row block of the column as one chunk."""
+    lib = N.load()
+    values = np.ascontiguousarray(values)
+    ctype = _column_type(values)
+    n = values.size
+    nm, nm_ptr = _nullmap_ptr(nullmap, n)
+    cap = lib.btr_compress_column_bound(ctype, n, block_rows)
+    out = np.empty(cap, dtype=np.uint8)
+    got = C.c_size_t()
+    opt = _options(max_cascade_depth, enable_for)
+    N.check(lib.btr_compress_column(ctype, values.ctypes.data, nm_ptr, n, block_rows, scheme.encode(),
+                                    C.byref(opt), threads, out.ctypes.data, cap, C.byref(got)))
+    return out[:got.value].copy()
+
+
+def compress_datablock(columns, max_cascade_depth=0, enable_for=False):
+    """Relation-level block (Datablock::compress(const Chunk&, BytesArray&)).
+    `columns`: list of (values, nullmap or None, scheme spec)."""
+    lib = N.load()
+    keep = []
+    arr = (N.ColumnInput * len(columns))()
+    n = None
+    cap = 64
+    for i, (values, nullmap, scheme) in enumerate(columns):
+        values = np.ascontiguousarray(values)
+        if n is None:
+            n = values.size
+        if values.size != n:
+            raise ValueError("all columns of a block must have the same row count")
+        nm, nm_ptr = _nullmap_ptr(nullmap, n)
+        spec = (scheme or "auto").encode()
+        keep.append((values, nm, spec))
+        arr[i].column_type = _column_type(values)
+        arr[i].values = values.ctypes.data
+        arr[i].nullmap = nm_ptr
+        arr[i].scheme_spec = spec
+        cap += lib.btr_compress_bound(arr[i].column_type, n) + 32
+    out = np.empty(cap, dtype=np.uint8)
+    got = C.c_size_t()
+    opt = _options(max_cascade_depth, enable_for)
+    N.check(lib.btr_compress_datablock(arr, len(columns), n or 0, C.byref(opt), out.ctypes.data, cap,
+                                       C.byref(got)))
+    return out[:got.value].copy()
+
+
+# ---------------------------------------------------------------------------------------------
+# GPU decode
+# ---------------------------------------------------------------------------------------------
+class GpuContext:
+    """btr_gpu_ctx: binds the library to one HIP device. Raises BtrError(BTR_ERR_DEVICE) when no
+    GPU (or no gfx950 code object) is available."""
+
+    def __init__(self, device=0):
+        self.lib = N.load()
+        self.device = device
+        h = C.c_void_p()
+        N.check(self.lib.btr_gpu_ctx_create(device, C.byref(h)))
+        self.handle = h
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.btr_gpu_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        self.close()
+
+    def decode_chunk_host(self, chunk, want_nullmap=False):
+        """Host in / host out: BtrReader::readColumn for one chunk."""
+        a = _as_u8(chunk)
+        info = chunk_info(a)
+        out = np.empty(info.tuple_count, dtype=_DTYPE[info.column_type])
+        nm = np.empty(info.tuple_count, dtype=np.uint8) if want_nullmap else None
+        N.check(self.lib.btr_gpu_decode_chunk_host(self.handle, a.ctypes.data, a.size, out.ctypes.data,
+                                                   out.nbytes, nm.ctypes.data if want_nullmap else None))
+        return (out, nm) if want_nullmap else out
+
+
+class DecodePlan:
+    """btr_gpu_plan over chunks whose compressed bytes are already resident on the device."""
+
+    def __init__(self, ctx, descs, keepalive=()):
+        self.ctx = ctx
+        self.lib = ctx.lib
+        self._keep = keepalive
+        arr = (N.ChunkDesc * len(descs))(*descs)
+        h = C.c_void_p()
+        N.check(self.lib.btr_gpu_plan_create(ctx.handle, arr, len(descs), C.byref(h)))
+        self.handle = h
+
+    @classmethod
+    def for_datablock(cls, ctx, host_block, dev_ptr, dsts, nullmap_dsts=None, keepalive=()):
+        self = cls.__new__(cls)
+        self.ctx, self.lib, self._keep = ctx, ctx.lib, keepalive
+        a = _as_u8(host_block)
+        n = len(dsts)
+        d = (C.c_void_p * n)(*dsts)
+        nm = (C.c_void_p * n)(*nullmap_dsts) if nullmap_dsts is not None else None
+        h = C.c_void_p()
+        N.check(self.lib.btr_gpu_plan_create_datablock(ctx.handle, a.ctypes.data, dev_ptr, a.size, d, nm, n,
+                                                       C.byref(h)))
+        self.handle = h
+        return self
+
+    @property
+    def stats(self):
+        s = N.PlanStats()
+        N.check(self.lib.btr_gpu_plan_stats(self.handle, C.byref(s)))
+        return s
+
+    def decode(self, stream=None):
+        N.check(self.lib.btr_gpu_decode(self.ctx.handle, self.handle, stream))
+
+    def check(self, stream=None):
+        st, first = C.c_uint32(), C.c_uint64()
+        N.check(self.lib.btr_gpu_plan_check(self.ctx.handle, self.handle, stream, C.byref(st), C.byref(first)))
+        return st.value
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.btr_gpu_plan_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        self.close()
+
+
+def current_stream_ptr():
+    """The raw hipStream_t of torch's current stream (0 = default stream)."""
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

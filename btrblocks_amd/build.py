@@ -1,0 +1,77 @@
+"""Builds the HIP shared library (gfx950 only) and the CPU oracle used by the tests.
+
+`python -m btrblocks_amd.build` compiles in-tree:
+  btrblocks_amd/libbtrblocks_amd.so   the product: C ABI + HIP kernels + CPU compressor
+  oracle/_build/libbtr_oracle.so      test infrastructure: CPU restatement of the decoder
+hipcc cross-compiles for gfx950 without a GPU present.
+"""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "btrblocks_amd", "csrc")
+LIB = os.path.join(ROOT, "btrblocks_amd", "libbtrblocks_amd.so")
+ORACLE_SRC = os.path.join(ROOT, "oracle", "btr_oracle.cpp")
+ORACLE_LIB = os.path.join(ROOT, "oracle", "_build", "libbtr_oracle.so")
+
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+
+def _newer(target, sources):
+    if not os.path.exists(target):
+        return False
+    t = os.path.getmtime(target)
+    return all(os.path.getmtime(s) <= t for s in sources)
+
+
+def _sources():
+    out = []
+    for d, _, files in os.walk(CSRC):
+        for f in files:
+            if f.endswith((".hip", ".cpp", ".h")):
+                out.append(os.path.join(d, f))
+    out.append(os.path.join(ROOT, "include", "btrblocks_amd.h"))
+    return out
+
+
+def build_library(force=False, verbose=False):
+    srcs = _sources()
+    if not force and _newer(LIB, srcs):
+        return LIB
+    cmd = [
+        HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+        "-ffp-contract=off", "-Wall", "-Wno-unused-function",
+        "-I", os.path.join(ROOT, "include"), "-I", CSRC,
+        os.path.join(CSRC, "c_api.hip"),
+        os.path.join(CSRC, "plan_builder.cpp"),
+        os.path.join(CSRC, "host", "compress.cpp"),
+        os.path.join(CSRC, "host", "codecs.cpp"),
+        "-o", LIB, "-lpthread",
+    ]
+    if verbose:
+        cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
+    subprocess.check_call(cmd)
+    return LIB
+
+
+def build_oracle(force=False):
+    if not force and _newer(ORACLE_LIB, [ORACLE_SRC]):
+        return ORACLE_LIB
+    os.makedirs(os.path.dirname(ORACLE_LIB), exist_ok=True)
+    subprocess.check_call([
+        "g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-pthread", "-Wall",
+        ORACLE_SRC, "-o", ORACLE_LIB,
+    ])
+    return ORACLE_LIB
+
+
+def main():
+    force = "--force" in sys.argv
+    verbose = "--verbose" in sys.argv
+    print(build_library(force, verbose))
+    print(build_oracle(force))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,606 @@
+// C ABI of the library (include/btrblocks_amd.h): host-side inspection, the CPU compressor
+// entry points, and the GPU decode entry points. Decoding never falls back to the CPU.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/btrblocks_amd.h"
+#include "btr_format.h"
+#include "host/compress.h"
+#include "plan.h"
+#include "plan_builder.h"
+
+using namespace btrfmt;
+
+// The kernels live in the same translation unit so that no relocatable device code is needed.
+#include "decode_kernels.hip"
+
+namespace {
+
+thread_local std::string g_error;
+
+btr_status fail(btr_status st, const std::string& msg) {
+  g_error = msg;
+  return st;
+}
+btr_status hip_fail(hipError_t e, const char* what) {
+  return fail(BTR_ERR_DEVICE, std::string(what) + ": " + hipGetErrorString(e));
+}
+#define HIP_TRY(expr)                                  \
+  do {                                                 \
+    hipError_t _e = (expr);                            \
+    if (_e != hipSuccess) return hip_fail(_e, #expr);  \
+  } while (0)
+
+struct DeviceGuard {
+  int prev = -1;
+  bool ok = true;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != dev) ok = hipSetDevice(dev) == hipSuccess;
+  }
+  ~DeviceGuard() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+};
+
+btr_status parse_chunk(const uint8_t* p, size_t bytes, btr_chunk_info* out) {
+  if (bytes < CHUNK_DATA) return fail(BTR_ERR_CORRUPT, "chunk shorter than its 12-byte envelope");
+  out->scheme = p[CHUNK_SCHEME];
+  out->nullmap_type = p[CHUNK_NM_TYPE];
+  out->column_type = p[CHUNK_COL_TYPE];
+  out->reserved = 0;
+  out->tuple_count = rd32(p + CHUNK_TUPLES);
+  if (out->column_type == COL_INTEGER)
+    out->decoded_bytes = (uint64_t)out->tuple_count * 4;
+  else if (out->column_type == COL_DOUBLE)
+    out->decoded_bytes = (uint64_t)out->tuple_count * 8;
+  else
+    return fail(BTR_ERR_UNSUPPORTED, "only integer and double columns are supported");
+  if (out->nullmap_type > NM_FLIPPED) return fail(BTR_ERR_CORRUPT, "unknown nullmap type");
+  if ((size_t)rd32(p + CHUNK_NM_OFFSET) > bytes - CHUNK_DATA)
+    return fail(BTR_ERR_CORRUPT, "nullmap offset past the end of the chunk");
+  return BTR_OK;
+}
+
+ColumnSource chunk_source(const uint8_t* host, size_t bytes, uint64_t dev, const btr_chunk_info& info,
+                          bool want_nullmap) {
+  ColumnSource cs{};
+  cs.host = host;
+  cs.bytes = bytes;
+  cs.dev_addr = dev;
+  cs.payload_off = CHUNK_DATA;
+  cs.nullmap_off = CHUNK_DATA + rd32(host + CHUNK_NM_OFFSET);
+  cs.column_type = info.column_type;
+  cs.scheme = info.scheme;
+  cs.nullmap_type = info.nullmap_type;
+  cs.tuple_count = info.tuple_count;
+  cs.want_nullmap = want_nullmap;
+  return cs;
+}
+
+btr_status parse_block_column(const uint8_t* p, size_t bytes, uint32_t column, btr_chunk_info* out,
+                              uint32_t* payload_off, uint32_t* nullmap_off) {
+  if (bytes < DB_ATTRS) return fail(BTR_ERR_CORRUPT, "block shorter than its header");
+  const uint32_t n = rd32(p + DB_COUNT), cols = rd32(p + DB_COLUMNS);
+  if (column >= cols) return fail(BTR_ERR_INVALID_ARGUMENT, "column index out of range");
+  if ((size_t)cols * DB_ATTR_BYTES > bytes - DB_ATTRS)
+    return fail(BTR_ERR_CORRUPT, "column table past the end of the block");
+  const uint8_t* m = p + DB_ATTRS + (size_t)DB_ATTR_BYTES * column;
+  out->scheme = m[CM_SCHEME];
+  out->column_type = m[CM_COL_TYPE];
+  out->nullmap_type = m[CM_NM_TYPE];
+  out->reserved = 0;
+  out->tuple_count = n;
+  out->decoded_bytes = (uint64_t)n * (out->column_type == COL_DOUBLE ? 8 : 4);
+  const uint32_t off = rd32(m + CM_OFFSET), nm = rd32(m + CM_NM_OFFSET);
+  if (off > bytes || nm > bytes) return fail(BTR_ERR_CORRUPT, "column offset past the end of the block");
+  if (out->nullmap_type > NM_FLIPPED) return fail(BTR_ERR_CORRUPT, "unknown nullmap type");
+  if (payload_off) *payload_off = off;
+  if (nullmap_off) *nullmap_off = nm;
+  return BTR_OK;
+}
+
+btrhost::Options to_options(const btr_compress_options* o) {
+  btrhost::Options opt;
+  if (o) {
+    if (o->max_cascade_depth) opt.max_cascade_depth = o->max_cascade_depth;
+    opt.enable_for = o->enable_for != 0;
+  }
+  return opt;
+}
+
+}  // namespace
+
+struct btr_gpu_ctx {
+  int device;
+};
+
+struct btr_gpu_plan {
+  int device = 0;
+  size_t n_items = 0;
+  WorkItem* d_items = nullptr;
+  uint8_t* d_programs = nullptr;
+  uint32_t* d_status = nullptr;
+  uint8_t* d_scratch = nullptr;
+  btr_plan_stats stats{};
+  std::vector<uint32_t> h_status;
+};
+
+namespace {
+
+// Uploads the built programs and work items of a plan.
+btr_status finish_plan(btr_gpu_ctx* ctx, std::vector<WorkItem>& items, std::vector<BuiltProgram>& progs,
+                       btr_plan_stats stats, btr_gpu_plan** out) {
+  DeviceGuard guard(ctx->device);
+  if (!guard.ok) return fail(BTR_ERR_DEVICE, "hipSetDevice failed");
+  auto plan = new btr_gpu_plan();
+  plan->device = ctx->device;
+  plan->n_items = items.size();
+  std::vector<uint8_t> blob;
+  uint64_t scratch = 0;
+  for (size_t i = 0; i < items.size(); i++) {
+    while (blob.size() % 16) blob.push_back(0);
+    items[i].prog_off = (uint32_t)blob.size();
+    items[i].prog_bytes = (uint32_t)progs[i].program.size();
+    blob.insert(blob.end(), progs[i].program.begin(), progs[i].program.end());
+    items[i].scratch = scratch;  // offset for now; rebased below
+    scratch += (progs[i].scratch_bytes + 255) / 256 * 256;
+    stats.max_lds_bytes = std::max(stats.max_lds_bytes, progs[i].lds_bytes);
+    stats.max_depth = std::max(stats.max_depth, progs[i].depth);
+    stats.needed_bytes += progs[i].needed_bytes;
+  }
+  stats.scratch_bytes = scratch;
+  stats.chunks = items.size();
+  plan->stats = stats;
+  auto cleanup = [&](btr_status st) {
+    btr_gpu_plan_destroy(plan);
+    return st;
+  };
+  if (blob.size() > 0xFFFFFFF0ull) return cleanup(fail(BTR_ERR_UNSUPPORTED, "plan programs exceed 4 GiB"));
+  hipError_t e;
+  if (scratch) {
+    if ((e = hipMalloc((void**)&plan->d_scratch, scratch)) != hipSuccess)
+      return cleanup(hip_fail(e, "hipMalloc(scratch)"));
+  }
+  for (size_t i = 0; i < items.size(); i++)
+    items[i].scratch = progs[i].scratch_bytes ? (uint64_t)(uintptr_t)plan->d_scratch + items[i].scratch : 0;
+  if (!items.empty()) {
+    if ((e = hipMalloc((void**)&plan->d_items, items.size() * sizeof(WorkItem))) != hipSuccess)
+      return cleanup(hip_fail(e, "hipMalloc(items)"));
+    if ((e = hipMalloc((void**)&plan->d_programs, blob.size() + 16)) != hipSuccess)
+      return cleanup(hip_fail(e, "hipMalloc(programs)"));
+    if ((e = hipMalloc((void**)&plan->d_status, items.size() * 4)) != hipSuccess)
+      return cleanup(hip_fail(e, "hipMalloc(status)"));
+    if ((e = hipMemcpy(plan->d_items, items.data(), items.size() * sizeof(WorkItem), hipMemcpyHostToDevice)) != hipSuccess)
+      return cleanup(hip_fail(e, "hipMemcpy(items)"));
+    if ((e = hipMemcpy(plan->d_programs, blob.data(), blob.size(), hipMemcpyHostToDevice)) != hipSuccess)
+      return cleanup(hip_fail(e, "hipMemcpy(programs)"));
+    if ((e = hipMemset(plan->d_status, 0, items.size() * 4)) != hipSuccess)
+      return cleanup(hip_fail(e, "hipMemset(status)"));
+  }
+  *out = plan;
+  return BTR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* btr_last_error(void) { return g_error.c_str(); }
+const char* btr_version(void) { return "btrblocks_amd 0.1 (gfx950)"; }
+
+// ---- inspection -------------------------------------------------------------------------------
+btr_status btr_chunk_inspect(const void* chunk, size_t bytes, btr_chunk_info* out) {
+  if (!chunk || !out) return fail(BTR_ERR_INVALID_ARGUMENT, "null argument");
+  return parse_chunk((const uint8_t*)chunk, bytes, out);
+}
+
+btr_status btr_chunk_describe(const void* chunk, size_t bytes, char* out, size_t cap) {
+  if (!chunk || !out || cap == 0) return fail(BTR_ERR_INVALID_ARGUMENT, "null argument");
+  btr_chunk_info info;
+  btr_status st = parse_chunk((const uint8_t*)chunk, bytes, &info);
+  if (st != BTR_OK) return st;
+  try {
+    BuiltProgram bp;
+    build_program(chunk_source((const uint8_t*)chunk, bytes, 0, info, false), bp);
+    snprintf(out, cap, "%s", bp.description.c_str());
+  } catch (const PlanError& e) {
+    return fail((btr_status)e.status, e.what());
+  }
+  return BTR_OK;
+}
+
+btr_status btr_part_chunk_count(const void* part, size_t bytes, uint32_t* out) {
+  if (!part || !out) return fail(BTR_ERR_INVALID_ARGUMENT, "null argument");
+  if (bytes < 4) return fail(BTR_ERR_CORRUPT, "part image shorter than its header");
+  const uint32_t n = rd32((const uint8_t*)part + PART_NUM_CHUNKS);
+  if ((size_t)n > (bytes - 4) / 4) return fail(BTR_ERR_CORRUPT, "chunk offset table past the end of the part");
+  *out = n;
+  return BTR_OK;
+}
+
+btr_status btr_part_chunk(const void* part, size_t bytes, uint32_t index, size_t* offset, size_t* length) {
+  uint32_t n;
+  btr_status st = btr_part_chunk_count(part, bytes, &n);
+  if (st != BTR_OK) return st;
+  if (index >= n) return fail(BTR_ERR_INVALID_ARGUMENT, "chunk index out of range");
+  const uint8_t* p = (const uint8_t*)part;
+  const size_t off = rd32(p + PART_OFFSETS + 4 * (size_t)index);
+  const size_t end = index + 1 < n ? rd32(p + PART_OFFSETS + 4 * (size_t)(index + 1)) : bytes;
+  if (off > end || end > bytes || end - off < CHUNK_DATA)
+    return fail(BTR_ERR_CORRUPT, "chunk offsets are not increasing or run past the part");
+  if (offset) *offset = off;
+  if (length) *length = end - off;
+  return BTR_OK;
+}
+
+btr_status btr_datablock_inspect(const void* block, size_t bytes, uint32_t* tuple_count, uint32_t* column_count) {
+  if (!block) return fail(BTR_ERR_INVALID_ARGUMENT, "null argument");
+  if (bytes < DB_ATTRS) return fail(BTR_ERR_CORRUPT, "block shorter than its header");
+  const uint8_t* p = (const uint8_t*)block;
+  if (tuple_count) *tuple_count = rd32(p + DB_COUNT);
+  if (column_count) *column_count = rd32(p + DB_COLUMNS);
+  return BTR_OK;
+}
+
+btr_status btr_datablock_column(const void* block, size_t bytes, uint32_t column, btr_chunk_info* out) {
+  if (!block || !out) return fail(BTR_ERR_INVALID_ARGUMENT, "null argument");
+  return parse_block_column((const uint8_t*)block, bytes, column, out, nullptr, nullptr);
+}
+
+// ---- compression (CPU) ----------------------------------------------------------------------------
+size_t btr_compress_bound(uint8_t column_type, uint32_t n) {
+  const size_t elem = column_type == COL_DOUBLE ? 8 : 4;
+  // Worst case is the UNCOMPRESSED fallback plus envelope, a u32-array nullmap and alignment.
+  return 64 + (size_t)n * elem + 8 + (size_t)n * 4;
+}
+
+btr_status btr_compress_chunk(uint8_t column_type, const void* values, const uint8_t* nullmap,
+                              uint32_t n, const char* scheme_spec, const btr_compress_options* options,
+                              void* out, size_t cap, size_t* out_bytes) {
+  if ((!values && n) || !out || !out_bytes) return fail(BTR_ERR_INVALID_ARGUMENT, "null argument");
+  if (column_type != COL_INTEGER && column_type != COL_DOUBLE)
+    return fail(BTR_ERR_UNSUPPORTED, "only integer and double columns are supported");
+  btrhost::Spec spec;
+  std::string err;
+  if (!btrhost::parse_spec(scheme_spec, column_type == COL_DOUBLE, spec, err))
+    return fail(BTR_ERR_INVALID_ARGUMENT, err);
+  try {
+    std::vector<uint8_t> buf;
+    btrhost::compress_chunk(column_type, values, nullmap, n, spec, to_options(options), buf);
+    if (buf.size() > cap) return fail(BTR_ERR_BUFFER_TOO_SMALL, "output buffer too small");
+    memcpy(out, buf.data(), buf.size());
+    *out_bytes = buf.size();
+  } catch (const std::exception& e) {
+    return fail(BTR_ERR_UNSUPPORTED, e.what());
+  }
+  return BTR_OK;
+}
+
+btr_status btr_compress_datablock(const btr_column_input* columns, uint32_t column_count, uint32_t n,
+                                  const btr_compress_options* options, void* out, size_t cap,
+                                  size_t* out_bytes) {
+  if (!columns || !out || !out_bytes) return fail(BTR_ERR_INVALID_ARGUMENT, "null argument");
+  std::vector<btrhost::ColumnInput> cols(column_count);
+  for (uint32_t c = 0; c < column_count; c++) {
+    cols[c].col_type = columns[c].column_type;
+    cols[c].values = columns[c].values;
+    cols[c].nullmap = columns[c].nullmap;
+    std::string err;
+    if (!btrhost::parse_spec(columns[c].scheme_spec, columns[c].column_type == COL_DOUBLE, cols[c].spec, err))
+      return fail(BTR_ERR_INVALID_ARGUMENT, err);
+  }
+  try {
+    std::vector<uint8_t> buf;
+    btrhost::compress_datablock(cols, n, to_options(options), buf);
+    if (buf.size() > cap) return fail(BTR_ERR_BUFFER_TOO_SMALL, "output buffer too small");
+    memcpy(out, buf.data(), buf.size());
+    *out_bytes = buf.size();
+  } catch (const std::exception& e) {
+    return fail(BTR_ERR_UNSUPPORTED, e.what());
+  }
+  return BTR_OK;
+}
+
+size_t btr_compress_column_bound(uint8_t column_type, uint64_t rows, uint32_t block_rows) {
+  if (block_rows == 0) block_rows = 65536;
+  const uint64_t chunks = (rows + block_rows - 1) / block_rows;
+  return 16 + chunks * 4 + chunks * (btr_compress_bound(column_type, block_rows) + 16);
+}
+
+btr_status btr_compress_column(uint8_t column_type, const void* values, const uint8_t* nullmap,
+                               uint64_t rows, uint32_t block_rows, const char* scheme_spec,
+                               const btr_compress_options* options, int threads, void* out, size_t cap,
+                               size_t* out_bytes) {
+  if ((!values && rows) || !out || !out_bytes) return fail(BTR_ERR_INVALID_ARGUMENT, "null argument");
+  if (column_type != COL_INTEGER && column_type != COL_DOUBLE)
+    return fail(BTR_ERR_UNSUPPORTED, "only integer and double columns are supported");
+  if (block_rows == 0) block_rows = 65536;
+  btrhost::Spec spec;
+  std::string err;
+  if (!btrhost::parse_spec(scheme_spec, column_type == COL_DOUBLE, spec, err))
+    return fail(BTR_ERR_INVALID_ARGUMENT, err);
+  const btrhost::Options opt = to_options(options);
+  const size_t elem = column_type == COL_DOUBLE ? 8 : 4;
+  const uint64_t n_chunks = (rows + block_rows - 1) / block_rows;
+  std::vector<std::vector<uint8_t>> chunks(n_chunks);
+  if (threads <= 0) threads = (int)std::thread::hardware_concurrency();
+  threads = std::max(1, std::min<int>(threads, (int)std::max<uint64_t>(1, n_chunks)));
+  std::atomic<uint64_t> next{0};
+  std::atomic<bool> failed{false};
+  std::string worker_err;
+  auto worker = [&]() {
+    for (;;) {
+      const uint64_t i = next.fetch_add(1);
+      if (i >= n_chunks || failed) break;
+      const uint64_t r0 = i * block_rows;
+      const uint32_t n = (uint32_t)std::min<uint64_t>(block_rows, rows - r0);
+      try {
+        btrhost::compress_chunk(column_type, (const uint8_t*)values + r0 * elem,
+                                nullmap ? nullmap + r0 : nullptr, n, spec, opt, chunks[i]);
+      } catch (const std::exception& e) {
+        if (!failed.exchange(true)) worker_err = e.what();
+      }
+    }
+  };
+  std::vector<std::thread> pool;
+  for (int t = 1; t < threads; t++) pool.emplace_back(worker);
+  worker();
+  for (auto& t : pool) t.join();
+  if (failed) return fail(BTR_ERR_UNSUPPORTED, worker_err);
+  // column part image: {u32 num_chunks; u32 offsets[]} then 16-byte aligned chunks
+  size_t total = 4 + 4 * n_chunks;
+  for (auto& c : chunks) total = (total + 15) / 16 * 16 + c.size();
+  if (total > 0xFFFFFFFFull) return fail(BTR_ERR_UNSUPPORTED, "column part image above 4 GiB; split the column");
+  if (total > cap) return fail(BTR_ERR_BUFFER_TOO_SMALL, "output buffer too small");
+  uint8_t* o = (uint8_t*)out;
+  memset(o, 0, 4 + 4 * n_chunks);
+  wr32(o, (uint32_t)n_chunks);
+  size_t pos = 4 + 4 * n_chunks;
+  for (uint64_t i = 0; i < n_chunks; i++) {
+    const size_t aligned = (pos + 15) / 16 * 16;
+    memset(o + pos, 0, aligned - pos);
+    pos = aligned;
+    wr32(o + PART_OFFSETS + 4 * i, (uint32_t)pos);
+    memcpy(o + pos, chunks[i].data(), chunks[i].size());
+    pos += chunks[i].size();
+  }
+  *out_bytes = pos;
+  return BTR_OK;
+}
+
+// ---- GPU ----------------------------------------------------------------------------------------------
+btr_status btr_gpu_ctx_create(int device, btr_gpu_ctx** out) {
+  if (!out) return fail(BTR_ERR_INVALID_ARGUMENT, "null argument");
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count == 0)
+    return fail(BTR_ERR_DEVICE, "no HIP device available: decoding requires an MI355X (gfx950) GPU");
+  if (device < 0 || device >= count) return fail(BTR_ERR_INVALID_ARGUMENT, "device index out of range");
+  DeviceGuard guard(device);
+  if (!guard.ok) return fail(BTR_ERR_DEVICE, "hipSetDevice failed");
+  hipFuncAttributes attr;
+  e = hipFuncGetAttributes(&attr, (const void*)btr_decode_kernel);
+  if (e != hipSuccess)
+    return fail(BTR_ERR_DEVICE, std::string("decode kernel has no code object for this device (built for gfx950): ") +
+                                    hipGetErrorString(e));
+  *out = new btr_gpu_ctx{device};
+  return BTR_OK;
+}
+
+void btr_gpu_ctx_destroy(btr_gpu_ctx* ctx) { delete ctx; }
+
+btr_status btr_gpu_plan_create(btr_gpu_ctx* ctx, const btr_chunk_desc* chunks, size_t n, btr_gpu_plan** out) {
+  if (!ctx || (!chunks && n) || !out) return fail(BTR_ERR_INVALID_ARGUMENT, "null argument");
+  std::vector<WorkItem> items(n);
+  std::vector<BuiltProgram> progs(n);
+  btr_plan_stats stats{};
+  for (size_t i = 0; i < n; i++) {
+    const btr_chunk_desc& d = chunks[i];
+    if (!d.host_src || !d.dev_src || !d.dev_dst)
+      return fail(BTR_ERR_INVALID_ARGUMENT, "chunk " + std::to_string(i) + ": null pointer");
+    btr_chunk_info info;
+    btr_status st = parse_chunk((const uint8_t*)d.host_src, d.src_bytes, &info);
+    if (st != BTR_OK) return fail(st, "chunk " + std::to_string(i) + ": " + g_error);
+    if (d.dst_bytes < info.decoded_bytes)
+      return fail(BTR_ERR_BUFFER_TOO_SMALL, "chunk " + std::to_string(i) + ": destination too small");
+    if ((uint64_t)(uintptr_t)d.dev_dst % 8 != 0)
+      return fail(BTR_ERR_MISALIGNED, "chunk " + std::to_string(i) + ": destination must be 8-byte aligned");
+    try {
+      build_program(chunk_source((const uint8_t*)d.host_src, d.src_bytes, (uint64_t)(uintptr_t)d.dev_src, info,
+                                 d.dev_nullmap_dst != nullptr),
+                    progs[i]);
+    } catch (const PlanError& e) {
+      return fail((btr_status)e.status, "chunk " + std::to_string(i) + ": " + e.what());
+    }
+    WorkItem& it = items[i];
+    it.src = (uint64_t)(uintptr_t)d.dev_src;
+    it.dst = (uint64_t)(uintptr_t)d.dev_dst;
+    it.nullmap_dst = (uint64_t)(uintptr_t)d.dev_nullmap_dst;
+    it.tuple_count = info.tuple_count;
+    it.src_bytes = (uint32_t)d.src_bytes;
+    stats.tuples += info.tuple_count;
+    stats.decoded_bytes += info.decoded_bytes;
+    stats.stored_bytes += d.src_bytes;
+    stats.needed_bytes += CHUNK_DATA;
+    if (d.dev_nullmap_dst) stats.nullmap_bytes += info.tuple_count;
+  }
+  return finish_plan(ctx, items, progs, stats, out);
+}
+
+btr_status btr_gpu_plan_create_datablock(btr_gpu_ctx* ctx, const void* host_block, const void* dev_block,
+                                         size_t bytes, void* const* dsts, uint8_t* const* nullmap_dsts,
+                                         uint32_t column_count, btr_gpu_plan** out) {
+  if (!ctx || !host_block || !dev_block || !dsts || !out) return fail(BTR_ERR_INVALID_ARGUMENT, "null argument");
+  const uint8_t* hb = (const uint8_t*)host_block;
+  uint32_t n, cols;
+  btr_status st = btr_datablock_inspect(host_block, bytes, &n, &cols);
+  if (st != BTR_OK) return st;
+  if (cols != column_count) return fail(BTR_ERR_INVALID_ARGUMENT, "column_count does not match the block");
+  std::vector<WorkItem> items(cols);
+  std::vector<BuiltProgram> progs(cols);
+  btr_plan_stats stats{};
+  stats.stored_bytes = bytes;
+  stats.needed_bytes = DB_ATTRS + (uint64_t)DB_ATTR_BYTES * cols;
+  for (uint32_t c = 0; c < cols; c++) {
+    btr_chunk_info info;
+    uint32_t off, nm;
+    st = parse_block_column(hb, bytes, c, &info, &off, &nm);
+    if (st != BTR_OK) return st;
+    if (info.column_type != COL_INTEGER && info.column_type != COL_DOUBLE)
+      return fail(BTR_ERR_UNSUPPORTED, "column " + std::to_string(c) + ": only integer and double columns are decoded");
+    if (!dsts[c]) return fail(BTR_ERR_INVALID_ARGUMENT, "column " + std::to_string(c) + ": null destination");
+    ColumnSource cs{};
+    cs.host = hb;
+    cs.bytes = bytes;
+    cs.dev_addr = (uint64_t)(uintptr_t)dev_block;
+    cs.payload_off = off;
+    cs.nullmap_off = nm;
+    cs.column_type = info.column_type;
+    cs.scheme = info.scheme;
+    cs.nullmap_type = info.nullmap_type;
+    cs.tuple_count = n;
+    cs.want_nullmap = nullmap_dsts && nullmap_dsts[c];
+    try {
+      build_program(cs, progs[c]);
+    } catch (const PlanError& e) {
+      return fail((btr_status)e.status, "column " + std::to_string(c) + ": " + e.what());
+    }
+    WorkItem& it = items[c];
+    it.src = (uint64_t)(uintptr_t)dev_block;
+    it.dst = (uint64_t)(uintptr_t)dsts[c];
+    it.nullmap_dst = cs.want_nullmap ? (uint64_t)(uintptr_t)nullmap_dsts[c] : 0;
+    it.tuple_count = n;
+    it.src_bytes = (uint32_t)bytes;
+    stats.tuples += n;
+    stats.decoded_bytes += info.decoded_bytes;
+    if (cs.want_nullmap) stats.nullmap_bytes += n;
+  }
+  return finish_plan(ctx, items, progs, stats, out);
+}
+
+void btr_gpu_plan_destroy(btr_gpu_plan* plan) {
+  if (!plan) return;
+  DeviceGuard guard(plan->device);
+  if (plan->d_items) (void)hipFree(plan->d_items);
+  if (plan->d_programs) (void)hipFree(plan->d_programs);
+  if (plan->d_status) (void)hipFree(plan->d_status);
+  if (plan->d_scratch) (void)hipFree(plan->d_scratch);
+  delete plan;
+}
+
+btr_status btr_gpu_plan_stats(const btr_gpu_plan* plan, btr_plan_stats* out) {
+  if (!plan || !out) return fail(BTR_ERR_INVALID_ARGUMENT, "null argument");
+  *out = plan->stats;
+  return BTR_OK;
+}
+
+btr_status btr_gpu_decode(btr_gpu_ctx* ctx, btr_gpu_plan* plan, void* hip_stream) {
+  if (!ctx || !plan) return fail(BTR_ERR_INVALID_ARGUMENT, "null argument");
+  if (plan->n_items == 0) return BTR_OK;
+  DeviceGuard guard(plan->device);
+  if (!guard.ok) return fail(BTR_ERR_DEVICE, "hipSetDevice failed");
+  hipLaunchKernelGGL(btr_decode_kernel, dim3((unsigned)plan->n_items), dim3(kBlockThreads),
+                     plan->stats.max_lds_bytes, (hipStream_t)hip_stream, plan->d_items, plan->d_programs,
+                     plan->d_status);
+  HIP_TRY(hipGetLastError());
+  return BTR_OK;
+}
+
+btr_status btr_gpu_plan_check(btr_gpu_ctx* ctx, btr_gpu_plan* plan, void* hip_stream, uint32_t* status_or,
+                              uint64_t* first_bad) {
+  if (!ctx || !plan) return fail(BTR_ERR_INVALID_ARGUMENT, "null argument");
+  DeviceGuard guard(plan->device);
+  HIP_TRY(hipStreamSynchronize((hipStream_t)hip_stream));
+  plan->h_status.resize(plan->n_items);
+  if (plan->n_items)
+    HIP_TRY(hipMemcpy(plan->h_status.data(), plan->d_status, plan->n_items * 4, hipMemcpyDeviceToHost));
+  uint32_t any = 0;
+  uint64_t first = ~0ull;
+  for (size_t i = 0; i < plan->n_items; i++) {
+    if (plan->h_status[i] && first == ~0ull) first = i;
+    any |= plan->h_status[i];
+  }
+  if (status_or) *status_or = any;
+  if (first_bad) *first_bad = first;
+  if (any)
+    return fail(BTR_ERR_CORRUPT, "malformed compressed stream in chunk " + std::to_string(first) +
+                                     " (status bits 0x" + [&] { char b[16]; snprintf(b, sizeof b, "%x", any); return std::string(b); }() + ")");
+  return BTR_OK;
+}
+
+btr_status btr_gpu_decode_chunk_host(btr_gpu_ctx* ctx, const void* chunk, size_t bytes, void* dst,
+                                     size_t dst_bytes, uint8_t* nullmap_dst) {
+  if (!ctx || !chunk || !dst) return fail(BTR_ERR_INVALID_ARGUMENT, "null argument");
+  btr_chunk_info info;
+  btr_status st = parse_chunk((const uint8_t*)chunk, bytes, &info);
+  if (st != BTR_OK) return st;
+  if (dst_bytes < info.decoded_bytes) return fail(BTR_ERR_BUFFER_TOO_SMALL, "destination too small");
+  DeviceGuard guard(ctx->device);
+  uint8_t *d_src = nullptr, *d_dst = nullptr, *d_nm = nullptr;
+  btr_gpu_plan* plan = nullptr;
+  auto done = [&](btr_status s) {
+    if (plan) btr_gpu_plan_destroy(plan);
+    if (d_src) (void)hipFree(d_src);
+    if (d_dst) (void)hipFree(d_dst);
+    if (d_nm) (void)hipFree(d_nm);
+    return s;
+  };
+  hipError_t e;
+  if ((e = hipMalloc((void**)&d_src, bytes + 16)) != hipSuccess) return done(hip_fail(e, "hipMalloc"));
+  if ((e = hipMalloc((void**)&d_dst, info.decoded_bytes + 16)) != hipSuccess) return done(hip_fail(e, "hipMalloc"));
+  if (nullmap_dst && (e = hipMalloc((void**)&d_nm, info.tuple_count + 16)) != hipSuccess)
+    return done(hip_fail(e, "hipMalloc"));
+  if ((e = hipMemcpy(d_src, chunk, bytes, hipMemcpyHostToDevice)) != hipSuccess) return done(hip_fail(e, "hipMemcpy"));
+  btr_chunk_desc d{chunk, d_src, bytes, d_dst, (size_t)info.decoded_bytes, d_nm};
+  if ((st = btr_gpu_plan_create(ctx, &d, 1, &plan)) != BTR_OK) return done(st);
+  if ((st = btr_gpu_decode(ctx, plan, nullptr)) != BTR_OK) return done(st);
+  if ((st = btr_gpu_plan_check(ctx, plan, nullptr, nullptr, nullptr)) != BTR_OK) return done(st);
+  if (info.decoded_bytes && (e = hipMemcpy(dst, d_dst, info.decoded_bytes, hipMemcpyDeviceToHost)) != hipSuccess)
+    return done(hip_fail(e, "hipMemcpy"));
+  if (nullmap_dst && info.tuple_count &&
+      (e = hipMemcpy(nullmap_dst, d_nm, info.tuple_count, hipMemcpyDeviceToHost)) != hipSuccess)
+    return done(hip_fail(e, "hipMemcpy"));
+  return done(BTR_OK);
+}
+
+btr_status btr_gpu_malloc(btr_gpu_ctx* ctx, size_t bytes, void** out) {
+  if (!ctx || !out) return fail(BTR_ERR_INVALID_ARGUMENT, "null argument");
+  DeviceGuard guard(ctx->device);
+  hipError_t e = hipMalloc(out, bytes ? bytes : 1);
+  if (e == hipErrorOutOfMemory) return fail(BTR_ERR_OUT_OF_MEMORY, "hipMalloc: out of device memory");
+  HIP_TRY(e);
+  return BTR_OK;
+}
+btr_status btr_gpu_free(btr_gpu_ctx* ctx, void* ptr) {
+  if (!ctx) return fail(BTR_ERR_INVALID_ARGUMENT, "null argument");
+  DeviceGuard guard(ctx->device);
+  HIP_TRY(hipFree(ptr));
+  return BTR_OK;
+}
+btr_status btr_gpu_upload(btr_gpu_ctx* ctx, void* dev_dst, const void* host_src, size_t bytes) {
+  if (!ctx) return fail(BTR_ERR_INVALID_ARGUMENT, "null argument");
+  DeviceGuard guard(ctx->device);
+  if (bytes) HIP_TRY(hipMemcpy(dev_dst, host_src, bytes, hipMemcpyHostToDevice));
+  return BTR_OK;
+}
+btr_status btr_gpu_download(btr_gpu_ctx* ctx, void* host_dst, const void* dev_src, size_t bytes) {
+  if (!ctx) return fail(BTR_ERR_INVALID_ARGUMENT, "null argument");
+  DeviceGuard guard(ctx->device);
+  if (bytes) HIP_TRY(hipMemcpy(host_dst, dev_src, bytes, hipMemcpyDeviceToHost));
+  return BTR_OK;
+}
+btr_status btr_gpu_synchronize(btr_gpu_ctx* ctx, void* hip_stream) {
+  if (!ctx) return fail(BTR_ERR_INVALID_ARGUMENT, "null argument");
+  DeviceGuard guard(ctx->device);
+  HIP_TRY(hipStreamSynchronize((hipStream_t)hip_stream));
+  return BTR_OK;
+}
+
+}  // extern "C"

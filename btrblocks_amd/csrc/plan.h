@@ -1,0 +1,131 @@
+// Decode plan: the flat, recursion-free program the host compiles from a chunk's header tree and
+// the HIP kernel interprets, one workgroup per chunk.
+//
+// The reference decodes a cascade by virtual recursion with per-level scratch vectors
+// (btrblocks/scheme/CompressionScheme.hpp:37-41, btrblocks/common/Units.hpp:118-123). On the GPU
+// the same tree is flattened into
+//   * sequences (Seq): arrays that live in LDS, in a per-chunk HBM scratch slice, in the
+//     compressed bytes themselves (raw dictionaries, UNCOMPRESSED children) or in the output;
+//   * pipes (Pipe): random-access value generators "value at row i" = a base (bit-unpack, run
+//     lookup, exception lookup, ...) followed by post-ops (dictionary gather, FOR bias);
+//   * steps (Step): the preparation order - build bit-unpack indexes, expand Roaring bitmaps,
+//     materialize short child streams (run tables, exception lists, patches) - ending with the
+//     step that materializes the root pipe into the output column.
+// Full-length child streams (dictionary codes, FOR deltas, Pseudodecimal digits/exponents) are
+// never materialized: they are evaluated on the fly inside the root step.
+#pragma once
+#include <stdint.h>
+
+namespace btrplan {
+
+enum : uint8_t { LOC_LDS = 0, LOC_SCRATCH = 1, LOC_SRC = 2, LOC_DST = 3, LOC_NULLMAP = 4 };
+
+struct Seq {
+  uint32_t off;    // byte offset inside its location (LDS offsets are relative to the table base)
+  uint32_t count;  // elements
+  uint8_t loc;
+  uint8_t esize;     // bytes per element: 1, 2, 4 or 8
+  uint8_t must_lds;  // host-side allocation hint only
+  uint8_t pad;
+};
+
+enum : uint8_t {
+  B_SEQ = 0,     // a[0] = seq id                                   (UNCOMPRESSED, materialized)
+  B_ONE = 1,     // a[0],a[1] = value bits                          (ONE_VALUE)
+  B_BP = 2,      // FastBinaryPacking<32>+VariableByte stream       (BP)
+  B_RLE = 3,     // run lookup through a start-flag bitmap          (RLE)
+  B_FREQ = 4,    // top value + exception bitmap                    (FREQUENCY)
+  B_DICTD = 5,   // double dictionary over an integer code pipe     (DICT, doubles)
+  B_PSEUDO = 6,  // digits * 10^-e with patches                     (PSEUDODECIMAL)
+  B_DBP = 7,     // FastBinaryPacking over 2n words = raw f64 bits  (DOUBLE_BP)
+};
+// Parameter slots per base
+//   B_BP / B_DBP : a0 payload byte offset in the chunk (4-byte aligned device address),
+//                  a1 stored word count, a2 seq id of the group index {word offset, header},
+//                  a3 values packed by FastBinaryPacking (multiple of 32), a4 seq id of the
+//                  decoded VariableByte tail (or NONE), a5 number of 128-value groups
+//   B_RLE        : a0 seq id of the start-flag bitmap, a1 seq id of its rank table,
+//                  a2 seq id of run values, a3 run count
+//   B_FREQ       : a0,a1 top value bits, a2 seq id bitmap, a3 seq id rank, a4 seq id exceptions
+//                  (or NONE), a5 cardinality
+//   B_DICTD      : a0 pipe id of the codes, a1 seq id of the dictionary
+//   B_PSEUDO     : a0 pipe id digits (or NONE), a1 pipe id exponents, a2 seq id patches (or
+//                  NONE), a3 seq id exception bitmap, a4 seq id rank, a5 converted_count
+constexpr uint32_t NONE = 0xFFFFFFFFu;
+
+enum : uint8_t { POST_DICT = 1, POST_ADD = 2 };
+struct PostOp {
+  uint8_t type;
+  uint8_t pad[3];
+  uint32_t arg;  // POST_DICT: seq id of the dictionary; POST_ADD: bias (wrapping add)
+};
+constexpr int MAX_POST = 2;
+
+struct Pipe {
+  uint8_t base;
+  uint8_t is_double;
+  uint8_t n_post;
+  uint8_t pad;
+  uint32_t count;  // rows this pipe can produce
+  uint32_t a[6];
+  PostOp post[MAX_POST];
+};
+
+enum : uint8_t {
+  S_BP_INDEX = 0,       // a0 pipe id: walk the group headers of a B_BP/B_DBP stream, decode its tail
+  S_MATERIALIZE = 1,    // a0 pipe id, a1 dst seq id
+  S_BITMAP_CLEAR = 2,   // a1 seq bitmap
+  S_BITMAP_SET = 3,     // a0 src byte offset, a1 seq bitmap, a2 element count, a3 first row of the
+                        // container (key << 16), a4 bit count, a5 element kind (SET_*)
+  S_BITMAP_STARTS = 4,  // a0 seq run lengths (s32), a1 seq bitmap, a3 bit count, a4 runs:
+                        // exclusive-scans the lengths and sets one bit per run start
+  S_BITMAP_EQ = 5,      // a0 pipe id, a1 seq bitmap, a3 bit count, a4 value: bit i = (pipe[i] == value)
+  S_BITMAP_RANK = 6,    // a1 seq bitmap, a2 seq rank, a3 bit count, a4 expected popcount (or NONE),
+                        // a5 status bit to raise on a mismatch
+  S_NULLMAP = 7,        // a0 nullmap type, a1 seq bitmap (REGULAR/FLIPPED, else NONE), a3 row count
+};
+// Element kinds of S_BITMAP_SET: the four member encodings of CRoaring's native serialization.
+enum : uint32_t { SET_ARRAY32 = 0, SET_ARRAY16 = 1, SET_BITSET = 2, SET_RUNS = 3 };
+struct Step {
+  uint8_t kind;
+  uint8_t pad[3];
+  uint32_t a[6];
+};
+
+struct ProgramHeader {
+  uint32_t n_steps;
+  uint32_t n_bp_steps;  // the leading S_BP_INDEX steps, run one per wave
+  uint32_t n_pipes;
+  uint32_t n_seqs;
+  uint32_t table_base;  // LDS byte offset where table space starts (after the program copy and
+                        // 64 bytes of reduction scratch)
+  uint32_t pad[3];
+};
+// A program is laid out as: ProgramHeader | Step[n_steps] | Pipe[n_pipes] | Seq[n_seqs]
+
+struct WorkItem {
+  uint64_t src;          // device address of the chunk envelope / block column payload base
+  uint64_t dst;          // device address of the decoded column (n * 4 or n * 8 bytes)
+  uint64_t nullmap_dst;  // device address of the byte-per-row nullmap, or 0
+  uint64_t scratch;      // device address of this item's scratch slice, or 0
+  uint32_t prog_off;     // byte offset of the program in the plan's program blob
+  uint32_t prog_bytes;
+  uint32_t tuple_count;
+  uint32_t src_bytes;
+};
+
+// Device status bits, one word per work item.
+enum : uint32_t {
+  ST_BP_HEADER = 1u << 0,   // a bit width above 32 or a group running past the stream
+  ST_BP_TAIL = 1u << 1,     // VariableByte tail does not hold the expected number of values
+  ST_RLE_COUNTS = 1u << 2,  // a run length <= 0 or lengths not adding up to the row count
+  ST_DICT_CODE = 1u << 3,   // dictionary code outside the dictionary
+  ST_PSEUDO = 1u << 4,      // exception count differs from tuple_count - converted_count
+  ST_ROARING = 1u << 5,     // member outside the row range or cardinality mismatch
+  ST_EXPONENT = 1u << 6,    // Pseudodecimal exponent index above 22
+};
+
+constexpr uint32_t kBlockThreads = 256;
+constexpr uint32_t kLdsCapBytes = 64 * 1024;
+
+}  // namespace btrplan

@@ -1,0 +1,543 @@
+// Host-side plan compiler (see plan_builder.h and plan.h).
+//
+// Header layouts followed, per scheme:
+//   UNCOMPRESSED   btrblocks/scheme/integer/Uncompressed.cpp:26-33, double/Uncompressed.cpp:25-31
+//   ONE_VALUE      btrblocks/scheme/integer/OneValue.cpp:30-39, double/OneValue.cpp:36-41
+//   DICT           btrblocks/scheme/templated/DynamicDictionary.hpp:7-11, 108-216
+//   RLE            btrblocks/scheme/templated/RLE.hpp:8-14, 133-250
+//   BP             btrblocks/scheme/integer/PBP.hpp:7-12, PBP.cpp:145-157
+//   FREQUENCY      btrblocks/scheme/templated/Frequency.hpp:12-18, 99-136
+//   FOR            btrblocks/scheme/integer/FOR.hpp:8-12, FOR.cpp:46-65
+//   PSEUDODECIMAL  btrblocks/scheme/double/Pseudodecimal.hpp:13-32, Pseudodecimal.cpp:348-452
+//   DOUBLE_BP      btrblocks/scheme/double/DoubleBP.hpp:7-11, DoubleBP.cpp:41-57
+//   DICTIONARY_8/16 btrblocks/scheme/templated/FixedDictionary.hpp:7-11, 56-71
+//   nullmap        btrblocks/extern/RoaringBitmap.cpp:8-26, 32-114
+#include "plan_builder.h"
+
+#include <algorithm>
+#include <cstring>
+
+#include "btr_format.h"
+
+namespace btrplan {
+using namespace btrfmt;
+
+namespace {
+
+constexpr int ST_CORRUPT = 2, ST_UNSUPPORTED = 3, ST_MISALIGNED = 6;
+constexpr int kMaxDepth = 8;
+// Optional tables (materialized children, dictionary copies) go to LDS while the workgroup's
+// total stays under this; beyond it they live in the chunk's HBM scratch slice.
+constexpr uint32_t kLdsSoftCap = 40 * 1024;
+constexpr uint32_t kDictLdsMaxBytes = 32 * 1024;
+
+struct Builder {
+  const ColumnSource& cs;
+  std::vector<Step> bp_steps, steps;
+  std::vector<Pipe> pipes;
+  std::vector<Seq> seqs;
+  uint64_t needed = 0;
+  uint32_t max_depth = 0;
+
+  [[noreturn]] void corrupt(const std::string& what) const { throw PlanError(ST_CORRUPT, what); }
+  void need(size_t off, size_t len, const char* what) const {
+    if (off > cs.bytes || len > cs.bytes - off)
+      corrupt(std::string(what) + " runs past the end of the compressed data");
+  }
+  uint8_t b(size_t off) const {
+    need(off, 1, "header");
+    return cs.host[off];
+  }
+  uint32_t w(size_t off) const {
+    need(off, 4, "header");
+    return rd32(cs.host + off);
+  }
+  uint16_t h(size_t off) const {
+    need(off, 2, "header");
+    return rd16(cs.host + off);
+  }
+
+  uint32_t add_seq(uint8_t loc, uint32_t off, uint32_t count, uint8_t esize, bool must_lds = false) {
+    Seq s{};
+    s.off = off;
+    s.count = count;
+    s.loc = loc;
+    s.esize = esize;
+    s.must_lds = must_lds ? 1 : 0;
+    seqs.push_back(s);
+    return (uint32_t)seqs.size() - 1;
+  }
+  uint32_t add_pipe(uint8_t base, bool is_double, uint32_t count) {
+    Pipe p{};
+    p.base = base;
+    p.is_double = is_double ? 1 : 0;
+    p.count = count;
+    for (auto& x : p.a) x = NONE;
+    pipes.push_back(p);
+    return (uint32_t)pipes.size() - 1;
+  }
+  void add_step(uint8_t kind, uint32_t a0 = NONE, uint32_t a1 = NONE, uint32_t a2 = NONE,
+                uint32_t a3 = NONE, uint32_t a4 = NONE, uint32_t a5 = NONE) {
+    Step s{};
+    s.kind = kind;
+    s.a[0] = a0, s.a[1] = a1, s.a[2] = a2, s.a[3] = a3, s.a[4] = a4, s.a[5] = a5;
+    (kind == S_BP_INDEX ? bp_steps : steps).push_back(s);
+  }
+
+  // The sequence holding a pipe's values: the pipe's own source when it is a bare array,
+  // otherwise a new table filled by a materialize step.
+  uint32_t as_seq(uint32_t pipe) {
+    const Pipe& p = pipes[pipe];
+    if (p.base == B_SEQ && p.n_post == 0) return p.a[0];
+    const uint32_t s = add_seq(LOC_LDS, 0, p.count, p.is_double ? 8 : 4);
+    add_step(S_MATERIALIZE, pipe, s);
+    return s;
+  }
+  uint32_t append_post(uint32_t pipe, uint8_t type, uint32_t arg) {
+    if (pipes[pipe].n_post == MAX_POST) {
+      const uint32_t s = as_seq(pipe);
+      pipe = add_pipe(B_SEQ, false, seqs[s].count);
+      pipes[pipe].a[0] = s;
+    }
+    Pipe& p = pipes[pipe];
+    p.post[p.n_post].type = type;
+    p.post[p.n_post].arg = arg;
+    p.n_post++;
+    return pipe;
+  }
+
+  struct Bitmap {
+    uint32_t bits, rank;
+  };
+  Bitmap add_bitmap(uint32_t nbits) {
+    const uint32_t words = nbits / 64 + 1;  // one spare word keeps rank(nbits) addressable
+    Bitmap bm;
+    bm.bits = add_seq(LOC_LDS, 0, words, 8, true);
+    bm.rank = add_seq(LOC_LDS, 0, words, 4, true);
+    return bm;
+  }
+
+  // Parses CRoaring's native serialization at `off`, emits the steps that expand it into `bm`
+  // and returns the cardinality. `count_bytes`: whether the decoder's reads count as needed.
+  uint32_t roaring_steps(size_t off, const Bitmap& bm, uint32_t nbits, bool count_bytes) {
+    add_step(S_BITMAP_CLEAR, NONE, bm.bits);
+    const uint8_t tag = b(off);
+    uint64_t used = 1;
+    uint32_t card_total = 0;
+    if (tag == ROAR_TAG_ARRAY_U32) {
+      const uint32_t card = w(off + 1);
+      if (card > nbits) corrupt("Roaring array holds more members than rows");
+      need(off + 5, (size_t)card * 4, "Roaring array");
+      add_step(S_BITMAP_SET, (uint32_t)(off + 5), bm.bits, card, 0, nbits, SET_ARRAY32);
+      used += 4 + (uint64_t)card * 4;
+      card_total = card;
+    } else if (tag == ROAR_TAG_CONTAINER) {
+      const size_t r = off + 1;
+      const uint32_t cookie = w(r);
+      uint32_t size;
+      size_t pos;
+      bool has_run = false;
+      size_t flags = 0;
+      if ((cookie & 0xFFFF) == ROAR_COOKIE_RUNS) {
+        size = (cookie >> 16) + 1;
+        has_run = true;
+        flags = r + 4;
+        need(flags, (size + 7) / 8, "Roaring run flags");
+        pos = r + 4 + (size + 7) / 8;
+      } else if (cookie == ROAR_COOKIE_NORUNS) {
+        size = w(r + 4);
+        pos = r + 8;
+      } else {
+        corrupt("bad Roaring cookie");
+      }
+      if (size > 65536) corrupt("bad Roaring container count");
+      const size_t desc = pos;
+      need(desc, (size_t)size * 4, "Roaring descriptive header");
+      pos += (size_t)size * 4;
+      if (!has_run || size >= ROAR_NO_OFFSET_THRESHOLD) pos += (size_t)size * 4;
+      for (uint32_t c = 0; c < size; c++) {
+        const uint32_t key = h(desc + 4 * (size_t)c);
+        const uint32_t card = (uint32_t)h(desc + 4 * (size_t)c + 2) + 1;
+        const uint32_t first_row = key << 16;
+        if (first_row >= nbits) corrupt("Roaring container beyond the row range");
+        const bool is_run = has_run && ((cs.host[flags + c / 8] >> (c % 8)) & 1);
+        if (is_run) {
+          const uint32_t n_runs = h(pos);
+          need(pos + 2, (size_t)n_runs * 4, "Roaring run container");
+          add_step(S_BITMAP_SET, (uint32_t)(pos + 2), bm.bits, n_runs, first_row, nbits, SET_RUNS);
+          pos += 2 + (size_t)n_runs * 4;
+        } else if (card <= ROAR_ARRAY_MAX_CARD) {
+          need(pos, (size_t)card * 2, "Roaring array container");
+          add_step(S_BITMAP_SET, (uint32_t)pos, bm.bits, card, first_row, nbits, SET_ARRAY16);
+          pos += (size_t)card * 2;
+        } else {
+          need(pos, 8192, "Roaring bitset container");
+          add_step(S_BITMAP_SET, (uint32_t)pos, bm.bits, 1024, first_row, nbits, SET_BITSET);
+          pos += 8192;
+        }
+        card_total += card;
+      }
+      used = pos - off;
+    } else {
+      corrupt("unknown Roaring serialization tag");
+    }
+    if (card_total > nbits) corrupt("Roaring bitmap holds more members than rows");
+    add_step(S_BITMAP_RANK, NONE, bm.bits, bm.rank, nbits, card_total, ST_ROARING);
+    if (count_bytes) needed += used;
+    return card_total;
+  }
+
+  // FastBinaryPacking<32> + VariableByte stream of `values` 32-bit values.
+  uint32_t bp_node(size_t off, uint32_t rows, uint32_t values, bool is_double, std::string& desc) {
+    const uint32_t words = w(off + BP_WORDS);
+    const uint32_t padding = b(off + BP_PADDING);
+    const size_t payload = off + BP_DATA + padding;
+    need(payload, (size_t)words * 4, "bit-packed payload");
+    if ((cs.dev_addr + payload) % 4 != 0)
+      throw PlanError(ST_MISALIGNED,
+                      "bit-packed payload is not 4-byte aligned at its device address; place the "
+                      "compressed bytes at the alignment they were compressed at (16 bytes)");
+    const uint32_t p = add_pipe(is_double ? B_DBP : B_BP, is_double, rows);
+    uint32_t rounded = 0;
+    if (values > 0) {
+      if (words == 0) corrupt("empty bit-packed payload");
+      rounded = w(payload);
+      if (rounded != values / FBP_MINIBLOCK * FBP_MINIBLOCK)
+        corrupt("bit-packed length word does not match the value count");
+    }
+    const uint32_t groups = (rounded + FBP_GROUP - 1) / FBP_GROUP;
+    Pipe& pp = pipes[p];
+    pp.a[0] = (uint32_t)payload;
+    pp.a[1] = words;
+    pp.a[3] = rounded;
+    pp.a[5] = groups;
+    const uint32_t index = add_seq(LOC_LDS, 0, groups + 1, 8, true);
+    const uint32_t tail = values > rounded ? add_seq(LOC_LDS, 0, FBP_MINIBLOCK, 4, true) : NONE;
+    pipes[p].a[2] = index;
+    pipes[p].a[4] = tail;
+    add_step(S_BP_INDEX, p);
+    needed += BP_DATA + (uint64_t)words * 4;
+    desc = is_double ? "DOUBLE_BP" : "BP";
+    return p;
+  }
+
+  template <typename CodeT>
+  uint32_t fixed_dict_node(size_t off, uint32_t n, bool is_double, std::string& desc) {
+    const uint32_t esz = is_double ? 8 : 4;
+    const uint32_t slots = is_double ? FDICT_D_SLOTS : FDICT_I_SLOTS;
+    const uint32_t codes_off = w(off + FDICT_CODES_OFFSET);
+    if (codes_off < slots) corrupt("bad fixed dictionary header");
+    const uint32_t dict_count = (codes_off - slots) / esz;
+    need(off + slots, (size_t)dict_count * esz, "fixed dictionary");
+    need(off + codes_off, (size_t)n * sizeof(CodeT), "fixed dictionary codes");
+    const uint32_t codes = add_seq(LOC_SRC, (uint32_t)(off + codes_off), n, sizeof(CodeT));
+    const uint32_t dict = add_seq(LOC_SRC, (uint32_t)(off + slots), dict_count, (uint8_t)esz);
+    needed += slots + (uint64_t)dict_count * esz + (uint64_t)n * sizeof(CodeT);
+    uint32_t cp = add_pipe(B_SEQ, false, n);
+    pipes[cp].a[0] = codes;
+    desc = sizeof(CodeT) == 1 ? "DICTIONARY_8" : "DICTIONARY_16";
+    if (!is_double) return append_post(cp, POST_DICT, dict);
+    const uint32_t p = add_pipe(B_DICTD, true, n);
+    pipes[p].a[0] = cp;
+    pipes[p].a[1] = dict;
+    return p;
+  }
+
+  // A dictionary small enough is staged in LDS; the copy is an ordinary materialize step.
+  uint32_t dict_seq(size_t off, uint32_t count, uint32_t esz, uint32_t rows) {
+    const uint32_t src = add_seq(LOC_SRC, (uint32_t)off, count, (uint8_t)esz);
+    if (count == 0 || (uint64_t)count * esz > kDictLdsMaxBytes || rows < 2 * count) return src;
+    const uint32_t p = add_pipe(B_SEQ, esz == 8, count);
+    pipes[p].a[0] = src;
+    const uint32_t lds = add_seq(LOC_LDS, 0, count, (uint8_t)esz);
+    add_step(S_MATERIALIZE, p, lds);
+    return lds;
+  }
+
+  template <bool IS_DOUBLE>
+  uint32_t rle_node(size_t off, uint32_t n, int depth, std::string& desc) {
+    const uint32_t runs = w(off + RLE_RUNS);
+    const uint32_t counts_off = w(off + RLE_COUNTS_OFFSET);
+    const uint8_t vs = b(off + RLE_VALUES_SCHEME), cs_code = b(off + RLE_COUNTS_SCHEME);
+    if (runs == 0 || runs > n) corrupt("RLE run count out of range");
+    const size_t data = off + RLE_DATA;
+    need(data, counts_off, "RLE values");
+    needed += RLE_DATA;
+    std::string dv, dc;
+    const uint32_t vp = IS_DOUBLE ? dbl_node(data, vs, runs, depth + 1, dv)
+                                  : int_node(data, vs, runs, false, depth + 1, dv);
+    const uint32_t cp = int_node(data + counts_off, cs_code, runs, false, depth + 1, dc);
+    // Run lengths are always copied: the start-flag step scans them in place.
+    const uint32_t lengths = add_seq(LOC_LDS, 0, runs, 4);
+    add_step(S_MATERIALIZE, cp, lengths);
+    const Bitmap bm = add_bitmap(n);
+    add_step(S_BITMAP_CLEAR, NONE, bm.bits);
+    add_step(S_BITMAP_STARTS, lengths, bm.bits, NONE, n, runs);
+    add_step(S_BITMAP_RANK, NONE, bm.bits, bm.rank, n, runs, ST_RLE_COUNTS);
+    const uint32_t values = as_seq(vp);
+    const uint32_t p = add_pipe(B_RLE, IS_DOUBLE, n);
+    pipes[p].a[0] = bm.bits;
+    pipes[p].a[1] = bm.rank;
+    pipes[p].a[2] = values;
+    pipes[p].a[3] = runs;
+    desc = "RLE(" + dv + "," + dc + ")";
+    return p;
+  }
+
+  template <bool IS_DOUBLE>
+  uint32_t frequency_node(size_t off, uint32_t n, int depth, std::string& desc) {
+    const uint32_t data_off = IS_DOUBLE ? FREQ_D_DATA : FREQ_I_DATA;
+    const uint32_t exc_off = w(off + (IS_DOUBLE ? FREQ_D_EXC_OFFSET : FREQ_I_EXC_OFFSET));
+    const uint8_t next = b(off + (IS_DOUBLE ? FREQ_D_NEXT : FREQ_I_NEXT));
+    need(off, data_off, "Frequency header");
+    needed += data_off;
+    const size_t data = off + data_off;
+    const Bitmap bm = add_bitmap(n);
+    const uint32_t card = roaring_steps(data, bm, n, true);
+    uint32_t exceptions = NONE;
+    std::string de = "-";
+    if (card > 0) {
+      const uint32_t ep = IS_DOUBLE ? dbl_node(data + exc_off, next, card, depth + 1, de)
+                                    : int_node(data + exc_off, next, card, false, depth + 1, de);
+      exceptions = as_seq(ep);
+    }
+    const uint32_t p = add_pipe(B_FREQ, IS_DOUBLE, n);
+    Pipe& pp = pipes[p];
+    pp.a[0] = rd32(cs.host + off);
+    pp.a[1] = IS_DOUBLE ? rd32(cs.host + off + 4) : 0;
+    pp.a[2] = bm.bits;
+    pp.a[3] = bm.rank;
+    pp.a[4] = exceptions;
+    pp.a[5] = card;
+    desc = "FREQUENCY(" + de + ")";
+    return p;
+  }
+
+  uint32_t int_node(size_t off, uint8_t scheme, uint32_t n, bool nullmap_allzeros, int depth,
+                    std::string& desc) {
+    if (depth > kMaxDepth) throw PlanError(ST_UNSUPPORTED, "cascade deeper than supported");
+    max_depth = std::max<uint32_t>(max_depth, (uint32_t)depth + 1);
+    switch (scheme) {
+      case I_UNCOMPRESSED: {
+        need(off, (size_t)n * 4, "UNCOMPRESSED data");
+        needed += (uint64_t)n * 4;
+        const uint32_t p = add_pipe(B_SEQ, false, n);
+        pipes[p].a[0] = add_seq(LOC_SRC, (uint32_t)off, n, 4);
+        desc = "UNCOMPRESSED";
+        return p;
+      }
+      case I_ONE_VALUE: {
+        const uint32_t v = w(off);
+        needed += 4;
+        const uint32_t p = add_pipe(B_ONE, false, n);
+        pipes[p].a[0] = v;
+        pipes[p].a[1] = 0;
+        desc = "ONE_VALUE";
+        return p;
+      }
+      case I_BP: return bp_node(off, n, n, false, desc);
+      case I_DICT: {
+        const uint8_t codes_scheme = b(off + DICT_CODES_SCHEME);
+        const uint32_t codes_off = w(off + DICT_CODES_OFFSET);
+        const size_t data = off + DICT_DATA;
+        need(data, codes_off, "dictionary");
+        const uint32_t dict_count = codes_off / 4;
+        needed += DICT_DATA + (uint64_t)dict_count * 4;
+        std::string dc;
+        uint32_t child = int_node(data + codes_off, codes_scheme, n, false, depth + 1, dc);
+        const uint32_t dict = dict_seq(data, dict_count, 4, n);
+        desc = "DICT(" + dc + ")";
+        return append_post(child, POST_DICT, dict);
+      }
+      case I_RLE: return rle_node<false>(off, n, depth, desc);
+      case I_FREQUENCY: return frequency_node<false>(off, n, depth, desc);
+      case I_FOR: {
+        const uint32_t bias = w(off + FOR_BIAS);
+        const uint8_t next = b(off + FOR_NEXT);
+        needed += FOR_DATA;
+        std::string dn;
+        // FOR hands the chunk's nullmap to its child and skips the add when every row is null
+        // (integer/FOR.cpp:53-59).
+        uint32_t child = int_node(off + FOR_DATA, next, n, nullmap_allzeros, depth + 1, dn);
+        desc = "FOR(" + dn + ")";
+        if (nullmap_allzeros) return child;
+        return append_post(child, POST_ADD, bias);
+      }
+      case I_DICTIONARY_8: return fixed_dict_node<uint8_t>(off, n, false, desc);
+      case I_DICTIONARY_16: return fixed_dict_node<uint16_t>(off, n, false, desc);
+      case I_PFOR:
+      case I_PFOR_DELTA:
+        throw PlanError(ST_UNSUPPORTED, "PFOR (SIMDFastPFor) streams are not supported yet");
+      case I_TRUNCATION_8:
+      case I_TRUNCATION_16:
+        // The reference cannot decode these either (integer/Truncation.hpp:88-97).
+        throw PlanError(ST_UNSUPPORTED, "Truncation schemes have no decoder");
+      default: corrupt("unknown integer scheme code " + std::to_string(scheme));
+    }
+  }
+
+  uint32_t dbl_node(size_t off, uint8_t scheme, uint32_t n, int depth, std::string& desc) {
+    if (depth > kMaxDepth) throw PlanError(ST_UNSUPPORTED, "cascade deeper than supported");
+    max_depth = std::max<uint32_t>(max_depth, (uint32_t)depth + 1);
+    switch (scheme) {
+      case D_UNCOMPRESSED: {
+        need(off, (size_t)n * 8, "UNCOMPRESSED data");
+        needed += (uint64_t)n * 8;
+        const uint32_t p = add_pipe(B_SEQ, true, n);
+        pipes[p].a[0] = add_seq(LOC_SRC, (uint32_t)off, n, 8);
+        desc = "UNCOMPRESSED";
+        return p;
+      }
+      case D_ONE_VALUE: {
+        need(off, 8, "ONE_VALUE");
+        needed += 8;
+        const uint32_t p = add_pipe(B_ONE, true, n);
+        pipes[p].a[0] = rd32(cs.host + off);
+        pipes[p].a[1] = rd32(cs.host + off + 4);
+        desc = "ONE_VALUE";
+        return p;
+      }
+      case D_DICT: {
+        const uint8_t codes_scheme = b(off + DICT_CODES_SCHEME);
+        const uint32_t codes_off = w(off + DICT_CODES_OFFSET);
+        const size_t data = off + DICT_DATA;
+        need(data, codes_off, "dictionary");
+        const uint32_t dict_count = codes_off / 8;
+        needed += DICT_DATA + (uint64_t)dict_count * 8;
+        std::string dc;
+        const uint32_t codes = int_node(data + codes_off, codes_scheme, n, false, depth + 1, dc);
+        const uint32_t dict = dict_seq(data, dict_count, 8, n);
+        const uint32_t p = add_pipe(B_DICTD, true, n);
+        pipes[p].a[0] = codes;
+        pipes[p].a[1] = dict;
+        desc = "DICT(" + dc + ")";
+        return p;
+      }
+      case D_RLE: return rle_node<true>(off, n, depth, desc);
+      case D_FREQUENCY: return frequency_node<true>(off, n, depth, desc);
+      case D_PSEUDODECIMAL: {
+        need(off, DEC_DATA, "Pseudodecimal header");
+        needed += DEC_DATA;
+        const uint32_t converted = w(off + DEC_CONVERTED);
+        if (converted > n) corrupt("Pseudodecimal converted_count above tuple count");
+        const uint8_t ns = b(off + DEC_NUMBERS_SCHEME), es = b(off + DEC_EXPONENTS_SCHEME),
+                      ps = b(off + DEC_PATCHES_SCHEME);
+        const uint32_t e_off = w(off + DEC_EXPONENTS_OFFSET), p_off = w(off + DEC_PATCHES_OFFSET);
+        const size_t data = off + DEC_DATA;
+        std::string dn = "-", de, dp = "-";
+        uint32_t digits = NONE;
+        if (converted > 0) digits = int_node(data, ns, converted, false, depth + 1, dn);
+        const uint32_t exps = int_node(data + e_off, es, n, false, depth + 1, de);
+        uint32_t patches = NONE;
+        if (n - converted > 0) {
+          const uint32_t pp = dbl_node(data + p_off, ps, n - converted, depth + 1, dp);
+          patches = as_seq(pp);
+        }
+        // The Roaring map of 4-row groups at exceptions_map_offset only steers the reference's
+        // AVX strategy; exception rows are found from the exponent stream instead.
+        const Bitmap bm = add_bitmap(n);
+        add_step(S_BITMAP_CLEAR, NONE, bm.bits);
+        add_step(S_BITMAP_EQ, exps, bm.bits, NONE, n, DEC_EXCEPTION_CODE);
+        add_step(S_BITMAP_RANK, NONE, bm.bits, bm.rank, n, n - converted, ST_PSEUDO);
+        const uint32_t p = add_pipe(B_PSEUDO, true, n);
+        Pipe& q = pipes[p];
+        q.a[0] = digits;
+        q.a[1] = exps;
+        q.a[2] = patches;
+        q.a[3] = bm.bits;
+        q.a[4] = bm.rank;
+        q.a[5] = converted;
+        desc = "PSEUDODECIMAL(" + dn + "," + de + "," + dp + ")";
+        return p;
+      }
+      case D_DOUBLE_BP: return bp_node(off, n, n * 2, true, desc);
+      case D_DICTIONARY_8: return fixed_dict_node<uint8_t>(off, n, true, desc);
+      case D_DICTIONARY_16: return fixed_dict_node<uint16_t>(off, n, true, desc);
+      default: corrupt("unknown double scheme code " + std::to_string(scheme));
+    }
+  }
+};
+
+uint32_t align_up(uint32_t v, uint32_t a) { return (v + a - 1) / a * a; }
+
+}  // namespace
+
+void build_program(const ColumnSource& src, BuiltProgram& out) {
+  if (src.column_type != COL_INTEGER && src.column_type != COL_DOUBLE)
+    throw PlanError(ST_UNSUPPORTED, "only integer and double columns are decoded on the GPU");
+  Builder bld{src, {}, {}, {}, {}, 0, 0};
+  const uint32_t n = src.tuple_count;
+  std::string desc;
+  uint32_t root;
+  if (src.column_type == COL_INTEGER)
+    root = bld.int_node(src.payload_off, src.scheme, n, src.nullmap_type == NM_ALLZEROS, 0, desc);
+  else
+    root = bld.dbl_node(src.payload_off, src.scheme, n, 0, desc);
+  const uint32_t dst = bld.add_seq(LOC_DST, 0, n, src.column_type == COL_DOUBLE ? 8 : 4);
+  bld.add_step(S_MATERIALIZE, root, dst);
+  if (src.want_nullmap) {
+    if (src.nullmap_type == NM_REGULAR || src.nullmap_type == NM_FLIPPED) {
+      const Builder::Bitmap bm = bld.add_bitmap(n);
+      bld.roaring_steps(src.nullmap_off, bm, n, true);
+      bld.add_step(S_NULLMAP, src.nullmap_type, bm.bits, NONE, n);
+    } else if (src.nullmap_type == NM_ALLONES || src.nullmap_type == NM_ALLZEROS) {
+      bld.add_step(S_NULLMAP, src.nullmap_type, NONE, NONE, n);
+    } else {
+      throw PlanError(ST_CORRUPT, "unknown nullmap type");
+    }
+  }
+
+  // ---- lay the program out, then place tables: mandatory LDS tables first, optional ones in
+  // LDS while the soft cap holds, the rest in the chunk's scratch slice.
+  const size_t n_steps = bld.bp_steps.size() + bld.steps.size();
+  const size_t prog_bytes = sizeof(ProgramHeader) + n_steps * sizeof(Step) +
+                            bld.pipes.size() * sizeof(Pipe) + bld.seqs.size() * sizeof(Seq);
+  const uint32_t table_base = align_up((uint32_t)prog_bytes, 16) + 64;  // + reduction scratch
+  uint64_t lds = 0, scratch = 0;
+  for (auto& s : bld.seqs)
+    if (s.loc == LOC_LDS && s.must_lds) {
+      s.off = (uint32_t)lds;
+      lds += align_up(s.count * s.esize, 16);
+    }
+  for (auto& s : bld.seqs)
+    if (s.loc == LOC_LDS && !s.must_lds) {
+      const uint64_t bytes = align_up(s.count * s.esize, 16);
+      if (table_base + lds + bytes <= kLdsSoftCap) {
+        s.off = (uint32_t)lds;
+        lds += bytes;
+      } else {
+        s.loc = LOC_SCRATCH;
+        s.off = (uint32_t)scratch;
+        scratch += bytes;
+      }
+    }
+  if (table_base + lds > kLdsCapBytes)
+    throw PlanError(ST_UNSUPPORTED, "decode tables of this chunk exceed the LDS budget (" +
+                                        std::to_string(table_base + lds) + " bytes)");
+  if (scratch > 0xFFFFFFFFull) throw PlanError(ST_UNSUPPORTED, "scratch need above 4 GiB");
+
+  out.program.assign(prog_bytes, 0);
+  uint8_t* p = out.program.data();
+  ProgramHeader hdr{};
+  hdr.n_steps = (uint32_t)n_steps;
+  hdr.n_bp_steps = (uint32_t)bld.bp_steps.size();
+  hdr.n_pipes = (uint32_t)bld.pipes.size();
+  hdr.n_seqs = (uint32_t)bld.seqs.size();
+  hdr.table_base = table_base;
+  memcpy(p, &hdr, sizeof(hdr));
+  p += sizeof(hdr);
+  if (!bld.bp_steps.empty()) memcpy(p, bld.bp_steps.data(), bld.bp_steps.size() * sizeof(Step));
+  p += bld.bp_steps.size() * sizeof(Step);
+  if (!bld.steps.empty()) memcpy(p, bld.steps.data(), bld.steps.size() * sizeof(Step));
+  p += bld.steps.size() * sizeof(Step);
+  memcpy(p, bld.pipes.data(), bld.pipes.size() * sizeof(Pipe));
+  p += bld.pipes.size() * sizeof(Pipe);
+  memcpy(p, bld.seqs.data(), bld.seqs.size() * sizeof(Seq));
+  out.lds_bytes = table_base + (uint32_t)lds;
+  out.scratch_bytes = (uint32_t)scratch;
+  out.needed_bytes = bld.needed;
+  out.depth = bld.max_depth;
+  out.description = desc;
+}
+
+}  // namespace btrplan

@@ -1,0 +1,91 @@
+"""Deterministic synthetic columns.
+
+The reference's generators (test/DatasetGenerator.cpp, tools/examples/compression.cpp:10-20) seed
+from time()/random_device, so their data is not reproducible; these restate the same
+distributions with fixed numpy seeds. Benchmark columns follow the shapes the baseline names:
+RLE, Dictionary and FOR+bitpack integer columns and a decimal-like double column.
+"""
+import numpy as np
+
+BLOCK_ROWS = 65536
+
+
+def example_runs(size=640000, unique=(1 << 12) - 1, runlength=40, seed=42, dtype=np.int32):
+    """tools/examples/compression.cpp:10-20: runs of `runlength` equal values < unique, one row
+    skipped between runs (the reference's loop increments i twice at a run boundary)."""
+    out = np.zeros(size, dtype=dtype)
+    rng = np.random.RandomState(seed)  # MT19937, like std::mt19937(seed)
+    i = 0
+    while i < size - runlength:
+        number = int(rng.randint(0, 2**32, dtype=np.uint64) % unique)
+        out[i:i + runlength] = number
+        i += runlength + 1
+    return out
+
+
+def int_rle(n, seed=1):
+    """values u % 100000 in runs of uniform length 16..64."""
+    rng = np.random.default_rng(seed)
+    runs = n // 16 + 1
+    lengths = rng.integers(16, 65, size=runs)
+    values = rng.integers(0, 100000, size=runs).astype(np.int32)
+    out = np.repeat(values, lengths)[:n]
+    return np.ascontiguousarray(out, dtype=np.int32)
+
+
+def int_dict(n, seed=2, distinct=4095):
+    """`distinct` random 31-bit values drawn uniformly."""
+    rng = np.random.default_rng(seed)
+    dictionary = np.unique(rng.integers(0, 2**31 - 1, size=distinct * 2).astype(np.int32))[:distinct]
+    return dictionary[rng.integers(0, dictionary.size, size=n)]
+
+
+def int_for(n, seed=3, bits=12):
+    """1e9 + u % 2^bits."""
+    rng = np.random.default_rng(seed)
+    return (1_000_000_000 + rng.integers(0, 1 << bits, size=n)).astype(np.int32)
+
+
+def double_decimal(n, seed=4, patch_fraction=0.01):
+    """k * 0.01 with k < 1e7 (two decimals), `patch_fraction` non-decimal patches and a few -0.0."""
+    rng = np.random.default_rng(seed)
+    k = rng.integers(0, 10_000_000, size=n)
+    out = k.astype(np.float64) * 0.01
+    m = max(1, int(n * patch_fraction)) if patch_fraction > 0 else 0
+    if m:
+        rows = rng.choice(n, size=m, replace=False)
+        out[rows] = (k[rows].astype(np.float64) + 1.0) / 3.0
+        out[rows[: max(1, m // 100)]] = -0.0
+    return out
+
+
+def int_frequency(n, seed=5, top_fraction=0.99):
+    """test/DatasetGenerator.cpp:290-325: one dominant value, rare random exceptions."""
+    rng = np.random.default_rng(seed)
+    out = np.full(n, 777_777, dtype=np.int32)
+    rows = rng.random(n) > top_fraction
+    out[rows] = rng.integers(0, 2**30, size=int(rows.sum())).astype(np.int32)
+    return out
+
+
+def double_frequency(n, seed=6, top_fraction=0.99):
+    rng = np.random.default_rng(seed)
+    out = np.full(n, 1234.5, dtype=np.float64)
+    rows = rng.random(n) > top_fraction
+    out[rows] = rng.uniform(-999999, 999999, size=int(rows.sum()))
+    return out
+
+
+def dictionary_values(n, distinct, seed=7, dtype=np.int32):
+    """test/DatasetGenerator.cpp:72-115, 134-177: `distinct` random values cycled."""
+    rng = np.random.default_rng(seed)
+    if dtype == np.int32:
+        d = rng.integers(-2**31, 2**31 - 1, size=distinct).astype(np.int32)
+    else:
+        d = rng.uniform(-999999, 999999, size=distinct)
+    return d[np.arange(n) % distinct]
+
+
+def random_nullmap(n, valid_fraction, seed=8):
+    rng = np.random.default_rng(seed)
+    return (rng.random(n) < valid_fraction).astype(np.uint8)

@@ -1,0 +1,181 @@
+/* btrblocks_amd - C ABI of the MI355X (gfx950) BtrBlocks decompression engine.
+ *
+ * The reference (maxi-k/btrblocks) has no FFI; its decode boundary is the C++ API
+ *   IntegerScheme::decompress / DoubleScheme::decompress   btrblocks/scheme/CompressionScheme.hpp:37-41, 70-74
+ *   BtrReader::readColumn + getters                        btrblocks/compression/BtrReader.hpp:12-45
+ *   Datablock::decompress / Datablock::compress            btrblocks/compression/Datablock.hpp:57-72
+ * Each entry point below names the reference interface it stands in for. All pointers are plain
+ * host or device addresses; no C++ or torch types cross this boundary.
+ *
+ * Decoding runs on the GPU only. Every decode entry point fails with BTR_ERR_DEVICE when no HIP
+ * device or no gfx950 code object is available; there is no CPU fallback. Compression and scheme
+ * selection stay on the CPU (btr_compress_*).
+ */
+#ifndef BTRBLOCKS_AMD_H
+#define BTRBLOCKS_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum btr_status {
+  BTR_OK = 0,
+  BTR_ERR_INVALID_ARGUMENT = 1,
+  BTR_ERR_CORRUPT = 2,      /* header/offset inconsistent with the supplied byte length          */
+  BTR_ERR_UNSUPPORTED = 3,  /* scheme without a decoder (the reference's Truncation, PFOR here)  */
+  BTR_ERR_BUFFER_TOO_SMALL = 4,
+  BTR_ERR_DEVICE = 5,       /* HIP runtime error, no device, or no gfx950 code object            */
+  BTR_ERR_MISALIGNED = 6,   /* bit-packed payload not 4-byte aligned at its device address       */
+  BTR_ERR_OUT_OF_MEMORY = 7
+} btr_status;
+
+/* Message of the last error on the calling thread (never NULL). */
+const char* btr_last_error(void);
+const char* btr_version(void);
+
+/* Column types and nullmap types: btrblocks/common/Units.hpp:45-57. */
+enum { BTR_COLUMN_INTEGER = 0, BTR_COLUMN_DOUBLE = 1, BTR_COLUMN_STRING = 2 };
+enum { BTR_NULLMAP_ALLONES = 0, BTR_NULLMAP_ALLZEROS = 1, BTR_NULLMAP_REGULAR = 2, BTR_NULLMAP_FLIPPED = 3 };
+
+/* ------------------------------------------------------------------------------------------
+ * Host-side inspection of compressed images (no GPU needed).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct btr_chunk_info {
+  uint32_t tuple_count;   /* BtrReader::getTupleCount,          BtrReader.hpp:35-37  */
+  uint8_t column_type;    /* BtrReader::getColumnType,          BtrReader.hpp:38     */
+  uint8_t scheme;         /* ColumnChunkMeta::compression_type, Datablock.hpp:13     */
+  uint8_t nullmap_type;   /* ColumnChunkMeta::nullmap_type,     Datablock.hpp:14     */
+  uint8_t reserved;
+  uint64_t decoded_bytes; /* BtrReader::getDecompressedDataSize, BtrReader.cpp:186-207 */
+} btr_chunk_info;
+
+/* One ColumnChunkMeta chunk (compression/Datablock.hpp:12-21). */
+btr_status btr_chunk_inspect(const void* chunk, size_t bytes, btr_chunk_info* out);
+/* Scheme tree of a chunk in text form, e.g. "RLE(DICT(BP),BP)": BtrReader::getSchemeDescription,
+ * BtrReader.cpp:76-97. Writes a NUL-terminated string of at most cap bytes. */
+btr_status btr_chunk_describe(const void* chunk, size_t bytes, char* out, size_t cap);
+/* Column part image {u32 num_chunks; u32 offsets[]} + chunks (storage/Chunk.hpp:95-98):
+ * BtrReader::getChunkCount / getChunkMetadata, BtrReader.hpp:28-39. */
+btr_status btr_part_chunk_count(const void* part, size_t bytes, uint32_t* out);
+btr_status btr_part_chunk(const void* part, size_t bytes, uint32_t index, size_t* offset, size_t* length);
+/* Relation-level block (DatablockMeta + ColumnMeta[], compression/Datablock.hpp:37-55). */
+btr_status btr_datablock_inspect(const void* block, size_t bytes, uint32_t* tuple_count, uint32_t* column_count);
+btr_status btr_datablock_column(const void* block, size_t bytes, uint32_t column, btr_chunk_info* out);
+
+/* ------------------------------------------------------------------------------------------
+ * Compression (CPU). Stands in for Datablock::compress(const InputChunk&, u8*)
+ * (compression/Datablock.cpp:66-148) and Datablock::compress(const Chunk&, BytesArray&)
+ * (:192-338). `scheme_spec` is "auto" (NULL = auto) or a forced cascade such as
+ * "rle(dict(bp),bp)", "for(bp)", "pseudodecimal(bp,bp,uncompressed)".
+ * ------------------------------------------------------------------------------------------ */
+typedef struct btr_compress_options {
+  uint8_t max_cascade_depth; /* 0 = default 3 (btrblocks.hpp:31,37) */
+  uint8_t enable_for;        /* the reference's ENABLE_FOR_SCHEME build flag */
+  uint8_t reserved[6];
+} btr_compress_options;
+
+size_t btr_compress_bound(uint8_t column_type, uint32_t tuple_count);
+btr_status btr_compress_chunk(uint8_t column_type, const void* values, const uint8_t* nullmap,
+                              uint32_t tuple_count, const char* scheme_spec,
+                              const btr_compress_options* options, void* out, size_t out_capacity,
+                              size_t* out_bytes);
+typedef struct btr_column_input {
+  uint8_t column_type;
+  const void* values;
+  const uint8_t* nullmap; /* byte per row, 1 = valid; NULL = all valid */
+  const char* scheme_spec;
+} btr_column_input;
+btr_status btr_compress_datablock(const btr_column_input* columns, uint32_t column_count,
+                                  uint32_t tuple_count, const btr_compress_options* options,
+                                  void* out, size_t out_capacity, size_t* out_bytes);
+
+/* Splits a column into blocks of `block_rows` rows (0 = 65536, btrblocks.hpp:24; the split of
+ * Relation::getRanges, storage/Relation.cpp:42-58), compresses each block as one chunk on
+ * `threads` host threads (0 = all) and writes a column part image (storage/Chunk.cpp:250-295).
+ * Unlike the reference's 16 MiB part files, the image holds all chunks of the column. */
+btr_status btr_compress_column(uint8_t column_type, const void* values, const uint8_t* nullmap,
+                               uint64_t rows, uint32_t block_rows, const char* scheme_spec,
+                               const btr_compress_options* options, int threads, void* out,
+                               size_t out_capacity, size_t* out_bytes);
+size_t btr_compress_column_bound(uint8_t column_type, uint64_t rows, uint32_t block_rows);
+
+/* ------------------------------------------------------------------------------------------
+ * GPU decode.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct btr_gpu_ctx btr_gpu_ctx;
+typedef struct btr_gpu_plan btr_gpu_plan;
+
+/* Binds to a HIP device. Fails with BTR_ERR_DEVICE if there is none. */
+btr_status btr_gpu_ctx_create(int device, btr_gpu_ctx** out);
+void btr_gpu_ctx_destroy(btr_gpu_ctx* ctx);
+
+/* One column chunk to decode. The compressed bytes must be resident on the device at `dev_src`
+ * (16-byte aligned, as in column part files) and readable on the host at `host_src`: headers are
+ * walked on the host once, when the plan is built. */
+typedef struct btr_chunk_desc {
+  const void* host_src;
+  const void* dev_src;
+  size_t src_bytes;
+  void* dev_dst;            /* tuple_count * 4 (integer) or * 8 (double) bytes, 8-byte aligned */
+  size_t dst_bytes;
+  uint8_t* dev_nullmap_dst; /* tuple_count bytes (BitmapWrapper::writeBITMAP), or NULL */
+} btr_chunk_desc;
+
+/* Builds the device-resident decode plan for n chunks: the counterpart of constructing
+ * BtrReader objects over column part images (BtrReader.cpp:12-15) - parsing, validation and
+ * table placement happen here, not in btr_gpu_decode. */
+btr_status btr_gpu_plan_create(btr_gpu_ctx* ctx, const btr_chunk_desc* chunks, size_t n, btr_gpu_plan** out);
+
+/* Plan over one relation-level block: every integer/double column becomes one work item
+ * (Datablock::decompress, Datablock.cpp:340-417). dsts[c] / nullmap_dsts[c] are device pointers
+ * (nullmap_dsts or its entries may be NULL). */
+btr_status btr_gpu_plan_create_datablock(btr_gpu_ctx* ctx, const void* host_block, const void* dev_block,
+                                         size_t bytes, void* const* dsts, uint8_t* const* nullmap_dsts,
+                                         uint32_t column_count, btr_gpu_plan** out);
+void btr_gpu_plan_destroy(btr_gpu_plan* plan);
+
+typedef struct btr_plan_stats {
+  uint64_t chunks;
+  uint64_t tuples;
+  uint64_t decoded_bytes;    /* bytes written to the value columns                              */
+  uint64_t nullmap_bytes;    /* bytes written to byte-per-row nullmaps                          */
+  uint64_t needed_bytes;     /* compressed bytes the decoder reads (headers + live payload)     */
+  uint64_t stored_bytes;     /* compressed bytes as stored (sum of src_bytes)                   */
+  uint64_t scratch_bytes;    /* HBM scratch for tables that did not fit in LDS                  */
+  uint32_t max_lds_bytes;    /* dynamic LDS per workgroup                                       */
+  uint32_t max_depth;
+} btr_plan_stats;
+btr_status btr_gpu_plan_stats(const btr_gpu_plan* plan, btr_plan_stats* out);
+
+/* Enqueues the decode of every chunk of the plan on `hip_stream` (a hipStream_t, NULL = default
+ * stream). Asynchronous; allocates nothing. Replaces the scheme.decompress(...) call inside
+ * BtrReader::readColumn (BtrReader.cpp:45-71) for all chunks at once. */
+btr_status btr_gpu_decode(btr_gpu_ctx* ctx, btr_gpu_plan* plan, void* hip_stream);
+
+/* Waits for the stream and reports malformed streams found by the kernels: *status_or is the OR
+ * of all per-chunk status words (0 = clean), *first_bad the first chunk with a non-zero word.
+ * Returns BTR_ERR_CORRUPT when any is set - the counterpart of the reference's
+ * Generic_Exception("Decompressing XPBP failed") (integer/PBP.cpp:44-47). */
+btr_status btr_gpu_plan_check(btr_gpu_ctx* ctx, btr_gpu_plan* plan, void* hip_stream,
+                              uint32_t* status_or, uint64_t* first_bad);
+
+/* Host-in / host-out decode of one chunk: BtrReader::readColumn (BtrReader.cpp:31-74) with the
+ * nullmap of BitmapWrapper::writeBITMAP (extern/RoaringBitmap.cpp:32-53). Copies the chunk to the
+ * device, decodes, copies the column back. `nullmap_dst` may be NULL. */
+btr_status btr_gpu_decode_chunk_host(btr_gpu_ctx* ctx, const void* chunk, size_t bytes, void* dst,
+                                     size_t dst_bytes, uint8_t* nullmap_dst);
+
+/* Thin wrappers over hipMalloc / hipFree / hipMemcpy for callers without a HIP toolchain. */
+btr_status btr_gpu_malloc(btr_gpu_ctx* ctx, size_t bytes, void** out);
+btr_status btr_gpu_free(btr_gpu_ctx* ctx, void* ptr);
+btr_status btr_gpu_upload(btr_gpu_ctx* ctx, void* dev_dst, const void* host_src, size_t bytes);
+btr_status btr_gpu_download(btr_gpu_ctx* ctx, void* host_dst, const void* dev_src, size_t bytes);
+btr_status btr_gpu_synchronize(btr_gpu_ctx* ctx, void* hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BTRBLOCKS_AMD_H */
