@@ -127,6 +127,8 @@ struct btr_gpu_plan {
   WorkItem* d_items = nullptr;
   uint8_t* d_programs = nullptr;
   uint32_t* d_status = nullptr;
+  uint32_t* d_order = nullptr;  // work item indices: integer columns first, then double columns
+  size_t n_int = 0, n_dbl = 0;
   uint8_t* d_scratch = nullptr;
   btr_plan_stats stats{};
   std::vector<uint32_t> h_status;
@@ -136,7 +138,7 @@ namespace {
 
 // Uploads the built programs and work items of a plan.
 btr_status finish_plan(btr_gpu_ctx* ctx, std::vector<WorkItem>& items, std::vector<BuiltProgram>& progs,
-                       btr_plan_stats stats, btr_gpu_plan** out) {
+                       const std::vector<uint8_t>& is_double, btr_plan_stats stats, btr_gpu_plan** out) {
   DeviceGuard guard(ctx->device);
   if (!guard.ok) return fail(BTR_ERR_DEVICE, "hipSetDevice failed");
   auto plan = new btr_gpu_plan();
@@ -183,6 +185,17 @@ btr_status finish_plan(btr_gpu_ctx* ctx, std::vector<WorkItem>& items, std::vect
       return cleanup(hip_fail(e, "hipMemcpy(programs)"));
     if ((e = hipMemset(plan->d_status, 0, items.size() * 4)) != hipSuccess)
       return cleanup(hip_fail(e, "hipMemset(status)"));
+    std::vector<uint32_t> order;
+    for (size_t i = 0; i < items.size(); i++)
+      if (!is_double[i]) order.push_back((uint32_t)i);
+    plan->n_int = order.size();
+    for (size_t i = 0; i < items.size(); i++)
+      if (is_double[i]) order.push_back((uint32_t)i);
+    plan->n_dbl = order.size() - plan->n_int;
+    if ((e = hipMalloc((void**)&plan->d_order, order.size() * 4)) != hipSuccess)
+      return cleanup(hip_fail(e, "hipMalloc(order)"));
+    if ((e = hipMemcpy(plan->d_order, order.data(), order.size() * 4, hipMemcpyHostToDevice)) != hipSuccess)
+      return cleanup(hip_fail(e, "hipMemcpy(order)"));
   }
   *out = plan;
   return BTR_OK;
@@ -386,7 +399,8 @@ btr_status btr_gpu_ctx_create(int device, btr_gpu_ctx** out) {
   DeviceGuard guard(device);
   if (!guard.ok) return fail(BTR_ERR_DEVICE, "hipSetDevice failed");
   hipFuncAttributes attr;
-  e = hipFuncGetAttributes(&attr, (const void*)btr_decode_kernel);
+  e = hipFuncGetAttributes(&attr, (const void*)btr_decode_int_kernel);
+  if (e == hipSuccess) e = hipFuncGetAttributes(&attr, (const void*)btr_decode_dbl_kernel);
   if (e != hipSuccess)
     return fail(BTR_ERR_DEVICE, std::string("decode kernel has no code object for this device (built for gfx950): ") +
                                     hipGetErrorString(e));
@@ -400,6 +414,7 @@ btr_status btr_gpu_plan_create(btr_gpu_ctx* ctx, const btr_chunk_desc* chunks, s
   if (!ctx || (!chunks && n) || !out) return fail(BTR_ERR_INVALID_ARGUMENT, "null argument");
   std::vector<WorkItem> items(n);
   std::vector<BuiltProgram> progs(n);
+  std::vector<uint8_t> is_double(n, 0);
   btr_plan_stats stats{};
   for (size_t i = 0; i < n; i++) {
     const btr_chunk_desc& d = chunks[i];
@@ -425,13 +440,14 @@ btr_status btr_gpu_plan_create(btr_gpu_ctx* ctx, const btr_chunk_desc* chunks, s
     it.nullmap_dst = (uint64_t)(uintptr_t)d.dev_nullmap_dst;
     it.tuple_count = info.tuple_count;
     it.src_bytes = (uint32_t)d.src_bytes;
+    is_double[i] = info.column_type == COL_DOUBLE;
     stats.tuples += info.tuple_count;
     stats.decoded_bytes += info.decoded_bytes;
     stats.stored_bytes += d.src_bytes;
     stats.needed_bytes += CHUNK_DATA;
     if (d.dev_nullmap_dst) stats.nullmap_bytes += info.tuple_count;
   }
-  return finish_plan(ctx, items, progs, stats, out);
+  return finish_plan(ctx, items, progs, is_double, stats, out);
 }
 
 btr_status btr_gpu_plan_create_datablock(btr_gpu_ctx* ctx, const void* host_block, const void* dev_block,
@@ -445,6 +461,7 @@ btr_status btr_gpu_plan_create_datablock(btr_gpu_ctx* ctx, const void* host_bloc
   if (cols != column_count) return fail(BTR_ERR_INVALID_ARGUMENT, "column_count does not match the block");
   std::vector<WorkItem> items(cols);
   std::vector<BuiltProgram> progs(cols);
+  std::vector<uint8_t> is_double(cols, 0);
   btr_plan_stats stats{};
   stats.stored_bytes = bytes;
   stats.needed_bytes = DB_ATTRS + (uint64_t)DB_ATTR_BYTES * cols;
@@ -478,11 +495,12 @@ btr_status btr_gpu_plan_create_datablock(btr_gpu_ctx* ctx, const void* host_bloc
     it.nullmap_dst = cs.want_nullmap ? (uint64_t)(uintptr_t)nullmap_dsts[c] : 0;
     it.tuple_count = n;
     it.src_bytes = (uint32_t)bytes;
+    is_double[c] = info.column_type == COL_DOUBLE;
     stats.tuples += n;
     stats.decoded_bytes += info.decoded_bytes;
     if (cs.want_nullmap) stats.nullmap_bytes += n;
   }
-  return finish_plan(ctx, items, progs, stats, out);
+  return finish_plan(ctx, items, progs, is_double, stats, out);
 }
 
 void btr_gpu_plan_destroy(btr_gpu_plan* plan) {
@@ -491,6 +509,7 @@ void btr_gpu_plan_destroy(btr_gpu_plan* plan) {
   if (plan->d_items) (void)hipFree(plan->d_items);
   if (plan->d_programs) (void)hipFree(plan->d_programs);
   if (plan->d_status) (void)hipFree(plan->d_status);
+  if (plan->d_order) (void)hipFree(plan->d_order);
   if (plan->d_scratch) (void)hipFree(plan->d_scratch);
   delete plan;
 }
@@ -506,10 +525,18 @@ btr_status btr_gpu_decode(btr_gpu_ctx* ctx, btr_gpu_plan* plan, void* hip_stream
   if (plan->n_items == 0) return BTR_OK;
   DeviceGuard guard(plan->device);
   if (!guard.ok) return fail(BTR_ERR_DEVICE, "hipSetDevice failed");
-  hipLaunchKernelGGL(btr_decode_kernel, dim3((unsigned)plan->n_items), dim3(kBlockThreads),
-                     plan->stats.max_lds_bytes, (hipStream_t)hip_stream, plan->d_items, plan->d_programs,
-                     plan->d_status);
-  HIP_TRY(hipGetLastError());
+  if (plan->n_int) {
+    hipLaunchKernelGGL(btr_decode_int_kernel, dim3((unsigned)plan->n_int), dim3(kBlockThreads),
+                       plan->stats.max_lds_bytes, (hipStream_t)hip_stream, plan->d_items, plan->d_order,
+                       plan->d_programs, plan->d_status);
+    HIP_TRY(hipGetLastError());
+  }
+  if (plan->n_dbl) {
+    hipLaunchKernelGGL(btr_decode_dbl_kernel, dim3((unsigned)plan->n_dbl), dim3(kBlockThreads),
+                       plan->stats.max_lds_bytes, (hipStream_t)hip_stream, plan->d_items,
+                       plan->d_order + plan->n_int, plan->d_programs, plan->d_status);
+    HIP_TRY(hipGetLastError());
+  }
   return BTR_OK;
 }
 

@@ -1,4 +1,4 @@
-// HIP decode kernel for gfx950 (MI355X): one 256-thread workgroup per compressed column chunk,
+// HIP decode kernels for gfx950 (MI355X): one 256-thread workgroup per compressed column chunk,
 // interpreting the flat program compiled by plan_builder.cpp (plan.h).
 //
 // What it replaces in the reference: the recursive virtual decompress() cascade
@@ -14,12 +14,15 @@
 //   2. every bit-packed stream gets a group index {word offset, width header} in LDS: the
 //      FastBinaryPacking layout interleaves one header word per 128 values with the payload, so
 //      header positions form a chain; one wave per stream walks it through 256-word register
-//      windows (coalesced loads, wave-uniform readlane steps), different streams on different waves;
+//      windows (coalesced, prefetched loads; wave-uniform readlane steps), different streams on
+//      different waves;
 //   3. short child streams (run lengths/values, exception lists, patches) are materialized into
 //      LDS (or an HBM scratch slice), start-flag / exception bitmaps get a popcount rank table;
 //   4. the root pipe is evaluated row by row - lane i of a wave produces row base+i, so stores
 //      are contiguous - with full-length children (codes, deltas, digits, exponents) bit-unpacked
 //      on the fly from the compressed stream; nothing but the decoded column is written to HBM.
+// The evaluation loops are instantiated per base kind so that each loop only keeps the state
+// of its own scheme in registers; integer and double columns run in separate kernels.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -84,6 +87,7 @@ __device__ inline u32 lds32(u32 off) { return *reinterpret_cast<const u32*>(lds_
 __device__ inline u64 lds64(u32 off) { return *reinterpret_cast<const u64*>(lds_raw + off); }
 __device__ inline void lds_st32(u32 off, u32 v) { *reinterpret_cast<u32*>(lds_raw + off) = v; }
 __device__ inline void lds_st64(u32 off, u64 v) { *reinterpret_cast<u64*>(lds_raw + off) = v; }
+__device__ inline u32 uniform(u32 v) { return __builtin_amdgcn_readfirstlane(v); }
 
 // ---- per-workgroup context (all wave-uniform) ------------------------------------------------
 struct Ctx {
@@ -167,37 +171,95 @@ __device__ inline void tab_st64(const Tab& t, u32 i, u64 v) {
 
 // ---- bitmap + rank ---------------------------------------------------------------------------
 // bits: u64 words in LDS; rank[w] = set bits in words [0, w).
-__device__ inline u32 rank_lt(u32 bits_off, u32 rank_off, u32 i, bool* member) {
+struct RankView {
+  u32 bits_off, rank_off;
+};
+// set bits strictly below row i, and whether row i itself is set
+__device__ inline u32 rank_lt(const RankView& r, u32 i, bool* member) {
   const u32 w = i >> 6, p = i & 63;
-  const u64 word = lds64(bits_off + 8 * w);
+  const u64 word = lds64(r.bits_off + 8 * w);
   *member = (word >> p) & 1;
-  return lds32(rank_off + 4 * w) + __popcll(word & ((1ull << p) - 1));
+  return lds32(r.rank_off + 4 * w) + __popcll(word & ((1ull << p) - 1));
+}
+// set bits at or below row i
+__device__ inline u32 rank_le(const RankView& r, u32 i) {
+  const u32 w = i >> 6, p = i & 63;
+  const u64 word = lds64(r.bits_off + 8 * w);
+  return lds32(r.rank_off + 4 * w) + __popcll(word & ((2ull << p) - 1));
+}
+
+// ---- bit-packed stream view --------------------------------------------------------------------
+struct BpView {
+  const u32* words;  // payload (4-byte aligned), words[0] = packed value count
+  u32 last_word;     // index of the last payload word (loads are clamped to it)
+  u32 rounded;       // values packed by FastBinaryPacking (multiple of 32)
+  u32 index_off;     // LDS offset of {word offset, header} per 128 values
+  u32 tail_off;      // LDS offset of the decoded VariableByte tail
+};
+
+__device__ inline BpView resolve_bp(const Ctx& c, const Pipe& p) {
+  BpView b;
+  b.words = reinterpret_cast<const u32*>(c.src + p.a[0]);
+  b.last_word = p.a[1] ? p.a[1] - 1 : 0;
+  b.rounded = p.a[3];
+  b.index_off = c.table_base + seq_at(c, p.a[2]).off;
+  b.tail_off = p.a[4] == NONE ? 0 : c.table_base + seq_at(c, p.a[4]).off;
+  return b;
+}
+
+// One value of a miniblock: `base_word` is the first word of the miniblock, value k occupies bits
+// [k*b, (k+1)*b) of its little-endian bit stream.
+__device__ inline u32 bp_extract(const BpView& e, u32 base_word, u32 b, u32 k) {
+  const u32 bit = k * b;
+  const u32 word = base_word + (bit >> 5);
+  const u32 w0 = word < e.last_word ? word : e.last_word;
+  const u32 w1 = word + 1 < e.last_word ? word + 1 : e.last_word;
+  const u32 lo = e.words[w0], hi = e.words[w1];
+  const u32 v = __builtin_amdgcn_alignbit(hi, lo, bit & 31);
+  return b >= 32 ? v : (v & ((1u << b) - 1u));
+}
+
+// Value `i` of a FastBinaryPacking<32>+VariableByte stream. Group g = i/128 starts at word
+// index[g].x with header index[g].y = (b0<<24)|(b1<<16)|(b2<<8)|b3; miniblock m = (i/32)%4 starts
+// after the header and the b_j words of the miniblocks before it.
+// ALIGNED: the wave's lanes evaluate 64 consecutive rows starting at a multiple of 64, so the
+// group is wave-uniform and its index entry is fetched once.
+template <bool ALIGNED>
+__device__ inline u32 bp_get(const BpView& e, u32 i) {
+  if (i >= e.rounded) return lds32(e.tail_off + 4 * ((i - e.rounded) & 31));
+  u32 off, hdr;
+  if (ALIGNED) {
+    const u32 g = uniform(i >> 7);
+    const u64 ih = lds64(e.index_off + 8 * g);
+    off = uniform((u32)ih);
+    hdr = uniform((u32)(ih >> 32));
+  } else {
+    const u64 ih = lds64(e.index_off + 8 * (i >> 7));
+    off = (u32)ih;
+    hdr = (u32)(ih >> 32);
+  }
+  const u32 m = (i >> 5) & 3, k = i & 31;
+  u32 b = (hdr >> (24 - 8 * m)) & 0xFF;
+  b = b > 32 ? 32 : b;
+  const u32 before = __builtin_amdgcn_sad_u8((u32)((u64)hdr >> (32 - 8 * m)), 0u, 0u);
+  return bp_extract(e, off + 1 + before, b, k);
 }
 
 // ---- resolved integer pipe -------------------------------------------------------------------
+constexpr u32 GEN = 255;  // template argument "base kind decided at run time"
+
 struct IntEval {
   u32 base;
   u32 count;
-  u32 k0;             // B_ONE value / B_FREQ top value / B_BP values packed by FastBinaryPacking
-  const u32* words;   // B_BP payload (4-byte aligned)
-  u32 last_word;      // B_BP: index of the last payload word
-  u32 index_off;      // B_BP: LDS offset of {word offset, header} per 128 values
-  u32 tail_off;       // B_BP: LDS offset of the decoded VariableByte tail
-  u32 bits_off, rank_off;  // B_RLE / B_FREQ
-  Tab tab;            // B_SEQ source / B_RLE run values / B_FREQ exceptions
+  u32 k0;       // B_ONE value / B_FREQ top value
+  BpView bp;    // B_BP
+  RankView rk;  // B_RLE / B_FREQ
+  Tab tab;      // B_SEQ source / B_RLE run values / B_FREQ exceptions
   u32 n_post;
   u32 post_type[MAX_POST];
   u32 post_bias[MAX_POST];
   Tab post_tab[MAX_POST];
 };
-
-__device__ inline void resolve_bp(const Ctx& c, const Pipe& p, IntEval& e) {
-  e.words = reinterpret_cast<const u32*>(c.src + p.a[0]);
-  e.last_word = p.a[1] ? p.a[1] - 1 : 0;
-  e.k0 = p.a[3];
-  e.index_off = c.table_base + seq_at(c, p.a[2]).off;
-  e.tail_off = p.a[4] == NONE ? 0 : c.table_base + seq_at(c, p.a[4]).off;
-}
 
 __device__ inline IntEval resolve_int(const Ctx& c, u32 pipe_id) {
   const Pipe& p = pipe_at(c, pipe_id);
@@ -205,23 +267,22 @@ __device__ inline IntEval resolve_int(const Ctx& c, u32 pipe_id) {
   e.base = p.base;
   e.count = p.count;
   e.k0 = 0;
-  e.words = nullptr;
-  e.last_word = 0;
-  e.index_off = e.tail_off = e.bits_off = e.rank_off = 0;
+  e.bp = BpView{nullptr, 0, 0, 0, 0};
+  e.rk = RankView{0, 0};
   e.tab = resolve_tab(c, NONE);
   switch (p.base) {
     case B_SEQ: e.tab = resolve_tab(c, p.a[0]); break;
     case B_ONE: e.k0 = p.a[0]; break;
-    case B_BP: resolve_bp(c, p, e); break;
+    case B_BP: e.bp = resolve_bp(c, p); break;
     case B_RLE:
-      e.bits_off = c.table_base + seq_at(c, p.a[0]).off;
-      e.rank_off = c.table_base + seq_at(c, p.a[1]).off;
+      e.rk.bits_off = c.table_base + seq_at(c, p.a[0]).off;
+      e.rk.rank_off = c.table_base + seq_at(c, p.a[1]).off;
       e.tab = resolve_tab(c, p.a[2]);
       break;
     case B_FREQ:
       e.k0 = p.a[0];
-      e.bits_off = c.table_base + seq_at(c, p.a[2]).off;
-      e.rank_off = c.table_base + seq_at(c, p.a[3]).off;
+      e.rk.bits_off = c.table_base + seq_at(c, p.a[2]).off;
+      e.rk.rank_off = c.table_base + seq_at(c, p.a[3]).off;
       e.tab = resolve_tab(c, p.a[4]);
       break;
     default: break;
@@ -236,55 +297,9 @@ __device__ inline IntEval resolve_int(const Ctx& c, u32 pipe_id) {
   return e;
 }
 
-// Value `i` of a FastBinaryPacking<32>+VariableByte stream. Group g = i/128 starts at word
-// index[g].x with header index[g].y = (b0<<24)|(b1<<16)|(b2<<8)|b3; miniblock m = (i/32)%4 starts
-// after the header and the b_j words of the miniblocks before it; value k = i%32 occupies bits
-// [k*b, (k+1)*b) of the miniblock's little-endian bit stream.
-__device__ inline u32 bp_get(const IntEval& e, u32 i) {
-  if (i >= e.k0) return lds32(e.tail_off + 4 * ((i - e.k0) & 31));
-  const u64 ih = lds64(e.index_off + 8 * (i >> 7));
-  const u32 off = (u32)ih, hdr = (u32)(ih >> 32);
-  const u32 m = (i >> 5) & 3, k = i & 31;
-  u32 b = (hdr >> (24 - 8 * m)) & 0xFF;
-  b = b > 32 ? 32 : b;
-  const u32 before = __builtin_amdgcn_sad_u8((u32)((u64)hdr >> (32 - 8 * m)), 0u, 0u);
-  const u32 bit = k * b;
-  const u32 word = off + 1 + before + (bit >> 5);
-  const u32 w0 = word < e.last_word ? word : e.last_word;
-  const u32 w1 = word + 1 < e.last_word ? word + 1 : e.last_word;
-  const u32 lo = e.words[w0], hi = e.words[w1];
-  const u32 v = __builtin_amdgcn_alignbit(hi, lo, bit & 31);
-  return b >= 32 ? v : (v & ((1u << b) - 1u));
-}
-
-__device__ inline u32 eval_int(const Ctx& c, const IntEval& e, u32 i) {
-  u32 v;
-  switch (e.base) {
-    case B_SEQ: v = tab_ld_small(e.tab, i); break;
-    case B_ONE: v = e.k0; break;
-    case B_BP: v = bp_get(e, i); break;
-    case B_RLE: {
-      // run index = (run starts at or before row i) - 1
-      const u32 w = i >> 6, p = i & 63;
-      const u64 word = lds64(e.bits_off + 8 * w);
-      u32 r = lds32(e.rank_off + 4 * w) + __popcll(word & ((2ull << p) - 1));
-      r = r ? r - 1 : 0;
-      r = r < e.tab.count ? r : e.tab.count - 1;
-      v = tab_ld32(e.tab, r);
-      break;
-    }
-    case B_FREQ: {
-      bool member;
-      u32 r = rank_lt(e.bits_off, e.rank_off, i, &member);
-      v = e.k0;
-      if (member) {
-        r = r < e.tab.count ? r : e.tab.count - 1;
-        v = tab_ld32(e.tab, r);
-      }
-      break;
-    }
-    default: v = 0; break;
-  }
+// Dictionary gathers and FOR bias adds queued behind the base value
+// (templated/DynamicDictionary.hpp:125-158: dest[i] = dict[codes[i]]; integer/FOR.cpp:62-64).
+__device__ inline u32 apply_posts(const Ctx& c, const IntEval& e, u32 v) {
 #pragma unroll
   for (int k = 0; k < MAX_POST; k++) {
     if (k < (int)e.n_post) {
@@ -303,15 +318,60 @@ __device__ inline u32 eval_int(const Ctx& c, const IntEval& e, u32 i) {
   return v;
 }
 
+template <u32 BASE, bool ALIGNED>
+__device__ inline u32 eval_int_base(const IntEval& e, u32 i) {
+  if (BASE == B_SEQ) return tab_ld_small(e.tab, i);
+  if (BASE == B_ONE) return e.k0;
+  if (BASE == B_BP) return bp_get<ALIGNED>(e.bp, i);
+  if (BASE == B_RLE) {
+    // run index = (run starts at or before row i) - 1   (templated/RLE.hpp:164-191)
+    u32 r = rank_le(e.rk, i);
+    r = r ? r - 1 : 0;
+    r = r < e.tab.count ? r : e.tab.count - 1;
+    return tab_ld32(e.tab, r);
+  }
+  if (BASE == B_FREQ) {
+    // top value unless the row is a bitmap member; the k-th member takes exceptions[k]
+    // (templated/Frequency.hpp:118-135)
+    bool member;
+    u32 r = rank_lt(e.rk, i, &member);
+    u32 v = e.k0;
+    if (member) {
+      r = r < e.tab.count ? r : e.tab.count - 1;
+      v = tab_ld32(e.tab, r);
+    }
+    return v;
+  }
+  return 0;
+}
+
+template <u32 BASE, bool ALIGNED>
+__device__ inline u32 eval_int(const Ctx& c, const IntEval& e, u32 i) {
+  u32 v;
+  if (BASE != GEN) {
+    v = eval_int_base<BASE, ALIGNED>(e, i);
+  } else {
+    switch (e.base) {
+      case B_SEQ: v = eval_int_base<B_SEQ, ALIGNED>(e, i); break;
+      case B_ONE: v = eval_int_base<B_ONE, ALIGNED>(e, i); break;
+      case B_BP: v = eval_int_base<B_BP, ALIGNED>(e, i); break;
+      case B_RLE: v = eval_int_base<B_RLE, ALIGNED>(e, i); break;
+      case B_FREQ: v = eval_int_base<B_FREQ, ALIGNED>(e, i); break;
+      default: v = 0; break;
+    }
+  }
+  return apply_posts(c, e, v);
+}
+
 // ---- resolved double pipe --------------------------------------------------------------------
 struct DblEval {
   u32 base;
   u32 count;
-  u32 k0, k1;          // B_ONE / B_FREQ value bits; B_PSEUDO: k0 = converted_count
-  u32 bits_off, rank_off;
-  Tab tab;             // B_SEQ / B_RLE values / B_FREQ exceptions / B_DICTD dictionary / B_PSEUDO patches
-  IntEval ia;          // B_DICTD codes / B_PSEUDO digits / B_DBP word stream
-  IntEval ib;          // B_PSEUDO exponents
+  u32 k0, k1;   // B_ONE / B_FREQ value bits; B_PSEUDO: k0 = converted_count
+  RankView rk;
+  Tab tab;      // B_SEQ / B_RLE values / B_FREQ exceptions / B_DICTD dictionary / B_PSEUDO patches
+  IntEval ia;   // B_DICTD codes / B_PSEUDO digits / B_DBP word stream
+  IntEval ib;   // B_PSEUDO exponents
 };
 
 __device__ inline DblEval resolve_dbl(const Ctx& c, u32 pipe_id) {
@@ -320,8 +380,10 @@ __device__ inline DblEval resolve_dbl(const Ctx& c, u32 pipe_id) {
   e.base = p.base;
   e.count = p.count;
   e.k0 = e.k1 = 0;
-  e.bits_off = e.rank_off = 0;
+  e.rk = RankView{0, 0};
   e.tab = resolve_tab(c, NONE);
+  e.ia.base = e.ib.base = B_ONE;
+  e.ia.n_post = e.ib.n_post = 0;
   switch (p.base) {
     case B_SEQ: e.tab = resolve_tab(c, p.a[0]); break;
     case B_ONE:
@@ -329,15 +391,15 @@ __device__ inline DblEval resolve_dbl(const Ctx& c, u32 pipe_id) {
       e.k1 = p.a[1];
       break;
     case B_RLE:
-      e.bits_off = c.table_base + seq_at(c, p.a[0]).off;
-      e.rank_off = c.table_base + seq_at(c, p.a[1]).off;
+      e.rk.bits_off = c.table_base + seq_at(c, p.a[0]).off;
+      e.rk.rank_off = c.table_base + seq_at(c, p.a[1]).off;
       e.tab = resolve_tab(c, p.a[2]);
       break;
     case B_FREQ:
       e.k0 = p.a[0];
       e.k1 = p.a[1];
-      e.bits_off = c.table_base + seq_at(c, p.a[2]).off;
-      e.rank_off = c.table_base + seq_at(c, p.a[3]).off;
+      e.rk.bits_off = c.table_base + seq_at(c, p.a[2]).off;
+      e.rk.rank_off = c.table_base + seq_at(c, p.a[3]).off;
       e.tab = resolve_tab(c, p.a[4]);
       break;
     case B_DICTD:
@@ -348,77 +410,74 @@ __device__ inline DblEval resolve_dbl(const Ctx& c, u32 pipe_id) {
       if (p.a[0] != NONE) e.ia = resolve_int(c, p.a[0]);
       e.ib = resolve_int(c, p.a[1]);
       e.tab = resolve_tab(c, p.a[2]);
-      e.bits_off = c.table_base + seq_at(c, p.a[3]).off;
-      e.rank_off = c.table_base + seq_at(c, p.a[4]).off;
+      e.rk.bits_off = c.table_base + seq_at(c, p.a[3]).off;
+      e.rk.rank_off = c.table_base + seq_at(c, p.a[4]).off;
       e.k0 = p.a[5];
       break;
     case B_DBP:
       e.ia.base = B_BP;
-      e.ia.n_post = 0;
-      resolve_bp(c, p, e.ia);
+      e.ia.bp = resolve_bp(c, p);
       break;
     default: break;
   }
   return e;
 }
 
+// IA / IB: base kinds of the nested integer pipes when known at compile time, else GEN.
+template <u32 BASE, u32 IA, u32 IB>
 __device__ inline u64 eval_dbl(const Ctx& c, const DblEval& e, u32 i) {
-  switch (e.base) {
-    case B_SEQ: return tab_ld64(e.tab, i);
-    case B_ONE: return ((u64)e.k1 << 32) | e.k0;
-    case B_RLE: {
-      const u32 w = i >> 6, p = i & 63;
-      const u64 word = lds64(e.bits_off + 8 * w);
-      u32 r = lds32(e.rank_off + 4 * w) + __popcll(word & ((2ull << p) - 1));
-      r = r ? r - 1 : 0;
-      r = r < e.tab.count ? r : e.tab.count - 1;
-      return tab_ld64(e.tab, r);
-    }
-    case B_FREQ: {
-      bool member;
-      u32 r = rank_lt(e.bits_off, e.rank_off, i, &member);
-      u64 v = ((u64)e.k1 << 32) | e.k0;
-      if (member) {
-        r = r < e.tab.count ? r : e.tab.count - 1;
-        v = tab_ld64(e.tab, r);
-      }
-      return v;
-    }
-    case B_DICTD: {
-      u32 code = eval_int(c, e.ia, i);
-      if (code >= e.tab.count) {
-        raise(c, ST_DICT_CODE);
-        code = e.tab.count ? e.tab.count - 1 : 0;
-      }
-      return e.tab.count ? tab_ld64(e.tab, code) : 0;
-    }
-    case B_PSEUDO: {
-      // double/Pseudodecimal.cpp:424-436: exponent 23 takes the next patch, anything else is
-      // double(int32 digits) * 10^-exponent - one exact conversion and one IEEE multiply.
-      const u32 ex = eval_int(c, e.ib, i);
-      bool member;
-      const u32 xr = rank_lt(e.bits_off, e.rank_off, i, &member);
-      if (ex == btrfmt::DEC_EXCEPTION_CODE) {
-        const u32 pi = xr < e.tab.count ? xr : e.tab.count - 1;
-        return e.tab.count ? tab_ld64(e.tab, pi) : 0;
-      }
-      u32 di = i - xr;
-      di = di < e.k0 ? di : (e.k0 ? e.k0 - 1 : 0);
-      const int digits = e.k0 ? (int)eval_int(c, e.ia, di) : 0;
-      u32 idx = ex & btrfmt::DEC_INDEX_MASK;
-      if (idx > btrfmt::DEC_MAX_EXPONENT) {
-        raise(c, ST_EXPONENT);
-        idx = btrfmt::DEC_MAX_EXPONENT;
-      }
-      const double r = (double)digits * kFractions[idx];
-      return (u64)__double_as_longlong(r);
-    }
-    case B_DBP: {
-      const u32 lo = bp_get(e.ia, 2 * i), hi = bp_get(e.ia, 2 * i + 1);
-      return ((u64)hi << 32) | lo;
-    }
-    default: return 0;
+  if (BASE == B_SEQ) return tab_ld64(e.tab, i);
+  if (BASE == B_ONE) return ((u64)e.k1 << 32) | e.k0;
+  if (BASE == B_RLE) {
+    u32 r = rank_le(e.rk, i);
+    r = r ? r - 1 : 0;
+    r = r < e.tab.count ? r : e.tab.count - 1;
+    return tab_ld64(e.tab, r);
   }
+  if (BASE == B_FREQ) {
+    bool member;
+    u32 r = rank_lt(e.rk, i, &member);
+    u64 v = ((u64)e.k1 << 32) | e.k0;
+    if (member) {
+      r = r < e.tab.count ? r : e.tab.count - 1;
+      v = tab_ld64(e.tab, r);
+    }
+    return v;
+  }
+  if (BASE == B_DICTD) {
+    u32 code = eval_int<IA, true>(c, e.ia, i);
+    if (code >= e.tab.count) {
+      raise(c, ST_DICT_CODE);
+      code = e.tab.count ? e.tab.count - 1 : 0;
+    }
+    return e.tab.count ? tab_ld64(e.tab, code) : 0;
+  }
+  if (BASE == B_PSEUDO) {
+    // double/Pseudodecimal.cpp:424-436: exponent 23 takes the next patch, anything else is
+    // double(int32 digits) * 10^-exponent - one exact conversion and one IEEE multiply.
+    const u32 ex = eval_int<IB, true>(c, e.ib, i);
+    bool member;
+    const u32 xr = rank_lt(e.rk, i, &member);
+    u32 di = i - xr;
+    di = di < e.k0 ? di : (e.k0 ? e.k0 - 1 : 0);
+    const int digits = e.k0 ? (int)eval_int<IA, false>(c, e.ia, di) : 0;
+    u32 idx = ex & btrfmt::DEC_INDEX_MASK;
+    if (ex != btrfmt::DEC_EXCEPTION_CODE && idx > btrfmt::DEC_MAX_EXPONENT) {
+      raise(c, ST_EXPONENT);
+    }
+    idx = idx > btrfmt::DEC_MAX_EXPONENT ? btrfmt::DEC_MAX_EXPONENT : idx;
+    u64 r = (u64)__double_as_longlong((double)digits * kFractions[idx]);
+    if (ex == btrfmt::DEC_EXCEPTION_CODE) {
+      const u32 pi = xr < e.tab.count ? xr : e.tab.count - 1;
+      r = e.tab.count ? tab_ld64(e.tab, pi) : 0;
+    }
+    return r;
+  }
+  if (BASE == B_DBP) {
+    const u32 lo = bp_get<false>(e.ia.bp, 2 * i), hi = bp_get<false>(e.ia.bp, 2 * i + 1);
+    return ((u64)hi << 32) | lo;
+  }
+  return 0;
 }
 
 // ---- block-wide exclusive scan of one value per thread ------------------------------------------
@@ -445,55 +504,93 @@ __device__ inline u32 block_exclusive_scan(const Ctx& c, u32 v, u32* total) {
 }
 
 // ---- step: bit-unpack group index ---------------------------------------------------------------
-// One wave per stream. Each iteration takes a 256-word window of the payload into registers
-// (four consecutive words per lane), turns every word into "group length if this word were a
-// header" (1 + sum of its four width bytes), and follows the chain of real headers through the
-// window with wave-uniform readlane steps.
+// One wave per stream. A window is 256 payload words, four consecutive words per lane. Every
+// word is turned into "group length if this word were a header" (1 + the sum of its four width
+// bytes, one byte per word); the chain of real headers is then followed through the window with
+// wave-uniform readlane steps. Windows are fetched four at a time, the next four while the
+// current four are walked. Group start positions collect in a register (lane g%64 keeps group g)
+// and are flushed to LDS every 64 groups; headers are gathered in parallel afterwards.
+struct Window {
+  u32 x0, x1, x2, x3;
+};
+
+__device__ inline Window load_window(const u32* words, u32 W, u32 wb, u32 lane) {
+  Window w;
+  const u32 w0 = wb + 4 * lane;
+  if (w0 + 4 <= W) {
+    uint4 v;
+    __builtin_memcpy(&v, words + w0, 16);
+    w.x0 = v.x, w.x1 = v.y, w.x2 = v.z, w.x3 = v.w;
+  } else {
+    w.x0 = w0 < W ? words[w0] : 0;
+    w.x1 = w0 + 1 < W ? words[w0 + 1] : 0;
+    w.x2 = w0 + 2 < W ? words[w0 + 2] : 0;
+    w.x3 = w0 + 3 < W ? words[w0 + 3] : 0;
+  }
+  return w;
+}
+
+__device__ inline u32 group_lengths(const Window& w) {
+  auto glen = [](u32 x) {
+    const u32 s = 1 + __builtin_amdgcn_sad_u8(x, 0u, 0u);
+    return s > 255 ? 255u : s;
+  };
+  return glen(w.x0) | (glen(w.x1) << 8) | (glen(w.x2) << 16) | (glen(w.x3) << 24);
+}
+
+constexpr u32 kWalkBatch = 4;  // windows in flight per batch
+
 __device__ void bp_index_wave(const Ctx& c, const Pipe& p) {
   const u32 lane = threadIdx.x & 63;
   const u32* words = reinterpret_cast<const u32*>(c.src + p.a[0]);
   const u32 W = p.a[1], rounded = p.a[3], groups = p.a[5];
   const u32 index_off = c.table_base + seq_at(c, p.a[2]).off;
-  u32 pos = 1, g = 0, bad = 0;
-  u32 x0 = 0, x1 = 0, x2 = 0, x3 = 0;
-  auto load_window = [&](u32 wb) {
-    const u32 w0 = wb + 4 * lane;
-    x0 = w0 < W ? words[w0] : 0;
-    x1 = w0 + 1 < W ? words[w0 + 1] : 0;
-    x2 = w0 + 2 < W ? words[w0 + 2] : 0;
-    x3 = w0 + 3 < W ? words[w0 + 3] : 0;
-  };
-  for (u32 wb = 0; g < groups; wb += 256) {
-    if (wb >= W) {
-      bad = 1;
-      break;
+  u32 pos = 1, g = 0, mine = 0;
+  Window cur[kWalkBatch], nxt[kWalkBatch];
+#pragma unroll
+  for (u32 k = 0; k < kWalkBatch; k++) cur[k] = load_window(words, W, 256 * k, lane);
+  for (u32 bb = 0; g < groups && bb < W; bb += 256 * kWalkBatch) {
+    const bool more = bb + 256 * kWalkBatch < W;
+    if (more) {
+#pragma unroll
+      for (u32 k = 0; k < kWalkBatch; k++) nxt[k] = load_window(words, W, bb + 256 * (kWalkBatch + k), lane);
     }
-    if (pos >= wb + 256) continue;
-    load_window(wb);
-    auto glen = [](u32 x) {
-      const u32 s = 1 + __builtin_amdgcn_sad_u8(x, 0u, 0u);
-      return s > 255 ? 255u : s;
-    };
-    const u32 d = glen(x0) | (glen(x1) << 8) | (glen(x2) << 16) | (glen(x3) << 24);
-    while (pos < wb + 256 && g < groups) {
-      const u32 rel = pos - wb;
-      const u32 l = rel >> 2, k = rel & 3;
-      const u32 dv = __builtin_amdgcn_readlane(d, l);
-      const u32 xs = k == 0 ? x0 : (k == 1 ? x1 : (k == 2 ? x2 : x3));
-      const u32 hv = __builtin_amdgcn_readlane(xs, l);
-      if (lane == 0) lds_st64(index_off + 8 * g, ((u64)hv << 32) | pos);
-      // every width byte must be <= 32
-      if ((hv & 0xC0C0C0C0u) || ((hv + 0x5F5F5F5Fu) & 0x80808080u)) bad = 1;
-      pos += (dv >> (8 * k)) & 0xFF;
-      g++;
+#pragma unroll
+    for (u32 k = 0; k < kWalkBatch; k++) {
+      const u32 wb = bb + 256 * k;
+      const u32 d = group_lengths(cur[k]);
+      while (pos < wb + 256 && g < groups) {
+        const u32 rel = pos - wb;
+        const u32 dv = __builtin_amdgcn_readlane(d, rel >> 2);
+        mine = lane == (g & 63) ? pos : mine;
+        pos += (dv >> (8 * (rel & 3))) & 0xFF;
+        g++;
+        if ((g & 63) == 0) lds_st32(index_off + 8 * (g - 64 + lane), mine);
+      }
+    }
+    if (more) {
+#pragma unroll
+      for (u32 k = 0; k < kWalkBatch; k++) cur[k] = nxt[k];
     }
   }
+  u32 bad = g < groups;  // the stream ended before all groups were found
+  const u32 found = g;
+  if ((found & 63) && lane < (found & 63)) lds_st32(index_off + 8 * ((found & ~63u) + lane), mine);
   if (pos > W) {
     bad = 1;
     pos = W;
   }
+  // parallel pass: fetch and validate the header word of every group
+  for (u32 gg = lane; gg < groups; gg += 64) {
+    u32 gp = gg < found ? lds32(index_off + 8 * gg) : 0;
+    gp = gp < W ? gp : (W ? W - 1 : 0);
+    const u32 hv = W ? words[gp] : 0;
+    // every width byte must be <= 32
+    if ((hv & 0xC0C0C0C0u) || ((hv + 0x5F5F5F5Fu) & 0x80808080u)) bad = 1;
+    lds_st64(index_off + 8 * gg, ((u64)hv << 32) | gp);
+  }
   if (lane == 0) lds_st64(index_off + 8 * groups, (u64)pos);
-  if (bad && lane == 0) raise(c, ST_BP_HEADER);
+  if (bad) raise(c, ST_BP_HEADER);
 
   // VariableByte tail (fewer than 32 values): 7 bits per byte, low group first, top bit ends a value.
   if (p.a[4] != NONE) {
@@ -522,41 +619,122 @@ __device__ void bp_index_wave(const Ctx& c, const Pipe& p) {
 // ---- step: materialize a pipe into a sequence ----------------------------------------------------
 constexpr u32 kUnroll = 4;
 
-__device__ void materialize(const Ctx& c, u32 pipe_id, u32 seq_id) {
+template <u32 BASE>
+__device__ void mat_int(const Ctx& c, const IntEval& e, const Tab& out, u32 count) {
   const u32 tid = threadIdx.x;
+  for (u32 base = 0; base < count; base += kBlockThreads * kUnroll) {
+    u32 v[kUnroll];
+#pragma unroll
+    for (u32 u = 0; u < kUnroll; u++) {
+      const u32 i = base + u * kBlockThreads + tid;
+      v[u] = eval_int<BASE, true>(c, e, i < count ? i : count - 1);
+    }
+#pragma unroll
+    for (u32 u = 0; u < kUnroll; u++) {
+      const u32 i = base + u * kBlockThreads + tid;
+      if (i < count) tab_st32(out, i, v[u]);
+    }
+  }
+}
+
+// Root loop for a bit-packed base: every wave takes whole 128-value groups, lane l produces
+// values l and l+64 of the group (miniblocks l/32 and 2+l/32), so the header and the miniblock
+// offsets are wave-uniform and a group's 128 values are stored as two contiguous 256-byte rows.
+constexpr u32 kGroupsPerIter = 2;
+
+__device__ void mat_int_bp(const Ctx& c, const IntEval& e, const Tab& out, u32 count) {
+  const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const BpView& bp = e.bp;
+  const u32 groups = (bp.rounded + btrfmt::FBP_GROUP - 1) / btrfmt::FBP_GROUP;
+  const u32 k = lane & 31;
+  const bool upper = lane >= 32;
+  for (u32 g0 = wave * kGroupsPerIter; g0 < groups; g0 += (kBlockThreads / 64) * kGroupsPerIter) {
+    u32 v[kGroupsPerIter][2];
+#pragma unroll
+    for (u32 j = 0; j < kGroupsPerIter; j++) {
+      const u32 g = g0 + j < groups ? g0 + j : groups - 1;
+      const u64 ih = lds64(bp.index_off + 8 * g);
+      const u32 off = uniform((u32)ih), hdr = uniform((u32)(ih >> 32));
+      u32 b0 = hdr >> 24, b1 = (hdr >> 16) & 0xFF, b2 = (hdr >> 8) & 0xFF, b3 = hdr & 0xFF;
+      b0 = b0 > 32 ? 32 : b0;
+      b1 = b1 > 32 ? 32 : b1;
+      b2 = b2 > 32 ? 32 : b2;
+      b3 = b3 > 32 ? 32 : b3;
+      const u32 first = off + 1;
+      // miniblocks 0/1 (value lane) and 2/3 (value lane + 64)
+      const u32 w_lo = upper ? first + b0 : first;
+      const u32 w_hi = upper ? first + b0 + b1 + b2 : first + b0 + b1;
+      v[j][0] = apply_posts(c, e, bp_extract(bp, w_lo, upper ? b1 : b0, k));
+      v[j][1] = apply_posts(c, e, bp_extract(bp, w_hi, upper ? b3 : b2, k));
+    }
+#pragma unroll
+    for (u32 j = 0; j < kGroupsPerIter; j++) {
+      const u32 i = (g0 + j) * btrfmt::FBP_GROUP + lane;
+      if (g0 + j < groups) {
+        if (i < bp.rounded) tab_st32(out, i, v[j][0]);
+        if (i + 64 < bp.rounded) tab_st32(out, i + 64, v[j][1]);
+      }
+    }
+  }
+  for (u32 i = bp.rounded + threadIdx.x; i < count; i += kBlockThreads)
+    tab_st32(out, i, apply_posts(c, e, lds32(bp.tail_off + 4 * ((i - bp.rounded) & 31))));
+}
+
+template <u32 BASE, u32 IA, u32 IB>
+__device__ void mat_dbl(const Ctx& c, const DblEval& e, const Tab& out, u32 count) {
+  const u32 tid = threadIdx.x;
+  for (u32 base = 0; base < count; base += kBlockThreads * kUnroll) {
+    u64 v[kUnroll];
+#pragma unroll
+    for (u32 u = 0; u < kUnroll; u++) {
+      const u32 i = base + u * kBlockThreads + tid;
+      v[u] = eval_dbl<BASE, IA, IB>(c, e, i < count ? i : count - 1);
+    }
+#pragma unroll
+    for (u32 u = 0; u < kUnroll; u++) {
+      const u32 i = base + u * kBlockThreads + tid;
+      if (i < count) tab_st64(out, i, v[u]);
+    }
+  }
+}
+
+template <bool DOUBLE_KERNEL>
+__device__ void materialize(const Ctx& c, u32 pipe_id, u32 seq_id) {
   const u32 count = pipe_at(c, pipe_id).count;
   const bool is_double = pipe_at(c, pipe_id).is_double;
   const Tab out = resolve_tab(c, seq_id);
   if (count == 0) return;
   if (!is_double) {
     const IntEval e = resolve_int(c, pipe_id);
-    for (u32 base = 0; base < count; base += kBlockThreads * kUnroll) {
-      u32 v[kUnroll];
-#pragma unroll
-      for (u32 u = 0; u < kUnroll; u++) {
-        const u32 i = base + u * kBlockThreads + tid;
-        v[u] = eval_int(c, e, i < count ? i : count - 1);
-      }
-#pragma unroll
-      for (u32 u = 0; u < kUnroll; u++) {
-        const u32 i = base + u * kBlockThreads + tid;
-        if (i < count) tab_st32(out, i, v[u]);
-      }
+    switch (e.base) {
+      case B_SEQ: mat_int<B_SEQ>(c, e, out, count); break;
+      case B_ONE: mat_int<B_ONE>(c, e, out, count); break;
+      case B_BP: mat_int_bp(c, e, out, count); break;
+      case B_RLE: mat_int<B_RLE>(c, e, out, count); break;
+      case B_FREQ: mat_int<B_FREQ>(c, e, out, count); break;
+      default: break;
     }
-  } else {
+  } else if (DOUBLE_KERNEL) {
     const DblEval e = resolve_dbl(c, pipe_id);
-    for (u32 base = 0; base < count; base += kBlockThreads * kUnroll) {
-      u64 v[kUnroll];
-#pragma unroll
-      for (u32 u = 0; u < kUnroll; u++) {
-        const u32 i = base + u * kBlockThreads + tid;
-        v[u] = eval_dbl(c, e, i < count ? i : count - 1);
-      }
-#pragma unroll
-      for (u32 u = 0; u < kUnroll; u++) {
-        const u32 i = base + u * kBlockThreads + tid;
-        if (i < count) tab_st64(out, i, v[u]);
-      }
+    switch (e.base) {
+      case B_SEQ: mat_dbl<B_SEQ, GEN, GEN>(c, e, out, count); break;
+      case B_ONE: mat_dbl<B_ONE, GEN, GEN>(c, e, out, count); break;
+      case B_RLE: mat_dbl<B_RLE, GEN, GEN>(c, e, out, count); break;
+      case B_FREQ: mat_dbl<B_FREQ, GEN, GEN>(c, e, out, count); break;
+      case B_DICTD:
+        if (e.ia.base == B_BP)
+          mat_dbl<B_DICTD, B_BP, GEN>(c, e, out, count);
+        else
+          mat_dbl<B_DICTD, GEN, GEN>(c, e, out, count);
+        break;
+      case B_PSEUDO:
+        if (e.ib.base == B_BP && (e.ia.base == B_BP || e.k0 == 0))
+          mat_dbl<B_PSEUDO, B_BP, B_BP>(c, e, out, count);
+        else
+          mat_dbl<B_PSEUDO, GEN, GEN>(c, e, out, count);
+        break;
+      case B_DBP: mat_dbl<B_DBP, B_BP, GEN>(c, e, out, count); break;
+      default: break;
     }
   }
 }
@@ -629,9 +807,8 @@ __device__ void bitmap_set(const Ctx& c, const Step& s) {
   if (bad) raise(c, ST_ROARING);
 }
 
-// Run lengths -> run starts (exclusive scan, in place) -> one start flag per run
-// (templated/RLE.hpp:164-191 expands runs back to back; the start of run r is the sum of the
-// lengths before it).
+// Run lengths -> run starts (exclusive scan) -> one start flag per run (templated/RLE.hpp:164-191
+// expands runs back to back; the start of run r is the sum of the lengths before it).
 __device__ void bitmap_starts(const Ctx& c, const Step& s) {
   const Tab len = resolve_tab(c, s.a[0]);
   const u32 bits_off = c.table_base + seq_at(c, s.a[1]).off;
@@ -662,7 +839,8 @@ __device__ void bitmap_eq(const Ctx& c, const Step& s) {
   const u32 nbits = s.a[3], value = s.a[4];
   for (u32 base = 0; base < nbits; base += kBlockThreads) {
     const u32 i = base + threadIdx.x;
-    const u32 v = eval_int(c, e, i < nbits ? i : nbits - 1);
+    const u32 ii = i < nbits ? i : nbits - 1;
+    const u32 v = e.base == B_BP ? eval_int<B_BP, true>(c, e, ii) : eval_int<GEN, true>(c, e, ii);
     const u64 m = __ballot(i < nbits && v == value);
     if ((threadIdx.x & 63) == 0 && (i >> 6) <= (nbits >> 6)) lds_st64(bits_off + 8 * (i >> 6), m);
   }
@@ -702,17 +880,16 @@ __device__ void write_nullmap(const Ctx& c, const Step& s) {
   }
 }
 
-}  // namespace
-
-extern "C" __global__ void __launch_bounds__(kBlockThreads)
-btr_decode_kernel(const WorkItem* __restrict__ items, const u8* __restrict__ programs,
-                  u32* __restrict__ status) {
-  const WorkItem it = items[blockIdx.x];
+template <bool DOUBLE_KERNEL>
+__device__ inline void decode_block(const WorkItem* __restrict__ items, const u32* __restrict__ order,
+                                    const u8* __restrict__ programs, u32* __restrict__ status) {
+  const u32 item = order[blockIdx.x];
+  const WorkItem it = items[item];
   const u32 tid = threadIdx.x;
   {
     const u32* prog = reinterpret_cast<const u32*>(programs + it.prog_off);
     for (u32 o = tid; o < it.prog_bytes / 4; o += kBlockThreads) lds_st32(4 * o, prog[o]);
-    if (tid == 0) status[blockIdx.x] = 0;  // later raise() calls are ordered behind the barrier
+    if (tid == 0) status[item] = 0;  // later raise() calls are ordered behind the barrier
   }
   __syncthreads();
   const ProgramHeader hdr = *reinterpret_cast<const ProgramHeader*>(lds_raw);
@@ -721,7 +898,7 @@ btr_decode_kernel(const WorkItem* __restrict__ items, const u8* __restrict__ pro
   c.dst = reinterpret_cast<u8*>(it.dst);
   c.nullmap = reinterpret_cast<u8*>(it.nullmap_dst);
   c.scratch = reinterpret_cast<u8*>(it.scratch);
-  c.status = status + blockIdx.x;
+  c.status = status + item;
   c.steps_off = sizeof(ProgramHeader);
   c.pipes_off = c.steps_off + hdr.n_steps * sizeof(Step);
   c.seqs_off = c.pipes_off + hdr.n_pipes * sizeof(Pipe);
@@ -736,7 +913,7 @@ btr_decode_kernel(const WorkItem* __restrict__ items, const u8* __restrict__ pro
   for (u32 s = hdr.n_bp_steps; s < hdr.n_steps; s++) {
     const Step st = step_at(c, s);
     switch (st.kind) {
-      case S_MATERIALIZE: materialize(c, st.a[0], st.a[1]); break;
+      case S_MATERIALIZE: materialize<DOUBLE_KERNEL>(c, st.a[0], st.a[1]); break;
       case S_BITMAP_CLEAR: bitmap_clear(c, st); break;
       case S_BITMAP_SET: bitmap_set(c, st); break;
       case S_BITMAP_STARTS: bitmap_starts(c, st); break;
@@ -747,4 +924,20 @@ btr_decode_kernel(const WorkItem* __restrict__ items, const u8* __restrict__ pro
     }
     __syncthreads();
   }
+}
+
+}  // namespace
+
+// `order` lists the work items this launch decodes (integer and double columns are launched
+// separately); status words are indexed by work item.
+extern "C" __global__ void __launch_bounds__(kBlockThreads)
+btr_decode_int_kernel(const WorkItem* __restrict__ items, const u32* __restrict__ order,
+                      const u8* __restrict__ programs, u32* __restrict__ status) {
+  decode_block<false>(items, order, programs, status);
+}
+
+extern "C" __global__ void __launch_bounds__(kBlockThreads)
+btr_decode_dbl_kernel(const WorkItem* __restrict__ items, const u32* __restrict__ order,
+                      const u8* __restrict__ programs, u32* __restrict__ status) {
+  decode_block<true>(items, order, programs, status);
 }

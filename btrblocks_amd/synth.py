@@ -26,8 +26,11 @@ def example_runs(size=640000, unique=(1 << 12) - 1, runlength=40, seed=42, dtype
 def int_rle(n, seed=1):
     """values u % 100000 in runs of uniform length 16..64."""
     rng = np.random.default_rng(seed)
-    runs = n // 16 + 1
+    runs = int(n / 40 * 1.05) + 64  # mean run length is 40; 5 % head-room, topped up below
     lengths = rng.integers(16, 65, size=runs)
+    while int(lengths.sum()) < n:
+        lengths = np.concatenate([lengths, rng.integers(16, 65, size=runs // 8 + 64)])
+    runs = lengths.size
     values = rng.integers(0, 100000, size=runs).astype(np.int32)
     out = np.repeat(values, lengths)[:n]
     return np.ascontiguousarray(out, dtype=np.int32)
