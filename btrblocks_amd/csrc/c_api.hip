@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <thread>
@@ -146,7 +147,11 @@ btr_status finish_plan(btr_gpu_ctx* ctx, std::vector<WorkItem>& items, std::vect
   plan->n_items = items.size();
   std::vector<uint8_t> blob;
   uint64_t scratch = 0;
+  const char* dbg = getenv("BTR_DEBUG_FLAGS");  // kernel timing diagnostics, see plan.h
+  const uint32_t debug_flags = dbg ? (uint32_t)atoi(dbg) : 0;
   for (size_t i = 0; i < items.size(); i++) {
+    items[i].debug_flags = debug_flags;
+    items[i].pad = 0;
     while (blob.size() % 16) blob.push_back(0);
     items[i].prog_off = (uint32_t)blob.size();
     items[i].prog_bytes = (uint32_t)progs[i].program.size();

@@ -87,7 +87,21 @@ __device__ inline u32 lds32(u32 off) { return *reinterpret_cast<const u32*>(lds_
 __device__ inline u64 lds64(u32 off) { return *reinterpret_cast<const u64*>(lds_raw + off); }
 __device__ inline void lds_st32(u32 off, u32 v) { *reinterpret_cast<u32*>(lds_raw + off) = v; }
 __device__ inline void lds_st64(u32 off, u64 v) { *reinterpret_cast<u64*>(lds_raw + off) = v; }
+// Values read from the program tables in LDS are the same in every lane, but the compiler must
+// be told: readfirstlane moves them to scalar registers so that loops over them stay scalar.
 __device__ inline u32 uniform(u32 v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ inline const u8* uniform_ptr(const u8* p) {
+  const u64 v = reinterpret_cast<u64>(p);
+  return reinterpret_cast<const u8*>(((u64)uniform((u32)(v >> 32)) << 32) | uniform((u32)v));
+}
+
+typedef u32 u32x2 __attribute__((ext_vector_type(2)));
+typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+// Raw buffer descriptor over `bytes` bytes at p: loads past the end return 0 instead of faulting,
+// so payload reads need no clamping.
+__device__ inline __amdgpu_buffer_rsrc_t make_rsrc(const void* p, u32 bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
 
 // ---- per-workgroup context (all wave-uniform) ------------------------------------------------
 struct Ctx {
@@ -111,6 +125,7 @@ __device__ inline const Seq& seq_at(const Ctx& c, u32 i) {
   return *reinterpret_cast<const Seq*>(lds_raw + c.seqs_off + i * sizeof(Seq));
 }
 __device__ inline void raise(const Ctx& c, u32 bits) { atomicOr(c.status, bits); }
+__device__ inline u32 seq_lds(const Ctx& c, u32 seq_id) { return c.table_base + uniform(seq_at(c, seq_id).off); }
 
 // A resolved sequence: LDS byte offset or global pointer.
 struct Tab {
@@ -121,7 +136,7 @@ struct Tab {
   u32 esize;
 };
 
-__device__ inline Tab resolve_tab(const Ctx& c, u32 seq_id) {
+__device__ __forceinline__ Tab resolve_tab(const Ctx& c, u32 seq_id) {
   Tab t;
   t.g = nullptr;
   t.lds = 0;
@@ -129,16 +144,17 @@ __device__ inline Tab resolve_tab(const Ctx& c, u32 seq_id) {
   t.loc = LOC_LDS;
   t.esize = 4;
   if (seq_id == NONE) return t;
-  const Seq s = seq_at(c, seq_id);
-  t.count = s.count;
-  t.loc = s.loc;
-  t.esize = s.esize;
-  switch (s.loc) {
-    case LOC_LDS: t.lds = c.table_base + s.off; break;
-    case LOC_SCRATCH: t.g = c.scratch + s.off; break;
-    case LOC_SRC: t.g = c.src + s.off; break;
-    case LOC_DST: t.g = c.dst + s.off; break;
-    default: t.g = c.nullmap + s.off; break;
+  const Seq& s = seq_at(c, seq_id);
+  const u32 off = uniform(s.off);
+  t.count = uniform(s.count);
+  t.loc = uniform(s.loc);
+  t.esize = uniform(s.esize);
+  switch (t.loc) {
+    case LOC_LDS: t.lds = c.table_base + off; break;
+    case LOC_SCRATCH: t.g = c.scratch + off; break;
+    case LOC_SRC: t.g = c.src + off; break;
+    case LOC_DST: t.g = c.dst + off; break;
+    default: t.g = c.nullmap + off; break;
   }
   return t;
 }
@@ -190,32 +206,30 @@ __device__ inline u32 rank_le(const RankView& r, u32 i) {
 
 // ---- bit-packed stream view --------------------------------------------------------------------
 struct BpView {
-  const u32* words;  // payload (4-byte aligned), words[0] = packed value count
-  u32 last_word;     // index of the last payload word (loads are clamped to it)
-  u32 rounded;       // values packed by FastBinaryPacking (multiple of 32)
-  u32 index_off;     // LDS offset of {word offset, header} per 128 values
-  u32 tail_off;      // LDS offset of the decoded VariableByte tail
+  const u8* base;  // payload (4-byte aligned); word 0 = packed value count
+  u32 bytes;       // payload length; buffer loads beyond it return 0
+  u32 rounded;     // values packed by FastBinaryPacking (multiple of 32)
+  u32 index_off;   // LDS offset of {word offset, header} per 128 values
+  u32 tail_off;    // LDS offset of the decoded VariableByte tail
 };
 
-__device__ inline BpView resolve_bp(const Ctx& c, const Pipe& p) {
+__device__ __forceinline__ BpView resolve_bp(const Ctx& c, const Pipe& p) {
   BpView b;
-  b.words = reinterpret_cast<const u32*>(c.src + p.a[0]);
-  b.last_word = p.a[1] ? p.a[1] - 1 : 0;
-  b.rounded = p.a[3];
-  b.index_off = c.table_base + seq_at(c, p.a[2]).off;
-  b.tail_off = p.a[4] == NONE ? 0 : c.table_base + seq_at(c, p.a[4]).off;
+  b.base = c.src + uniform(p.a[0]);
+  b.bytes = uniform(p.a[1]) * 4;
+  b.rounded = uniform(p.a[3]);
+  b.index_off = seq_lds(c, uniform(p.a[2]));
+  const u32 tail = uniform(p.a[4]);
+  b.tail_off = tail == NONE ? 0 : seq_lds(c, tail);
   return b;
 }
 
 // One value of a miniblock: `base_word` is the first word of the miniblock, value k occupies bits
-// [k*b, (k+1)*b) of its little-endian bit stream.
-__device__ inline u32 bp_extract(const BpView& e, u32 base_word, u32 b, u32 k) {
+// [k*b, (k+1)*b) of its little-endian bit stream. One 8-byte buffer load covers any value.
+__device__ __forceinline__ u32 bp_extract(__amdgpu_buffer_rsrc_t rsrc, u32 base_word, u32 b, u32 k) {
   const u32 bit = k * b;
-  const u32 word = base_word + (bit >> 5);
-  const u32 w0 = word < e.last_word ? word : e.last_word;
-  const u32 w1 = word + 1 < e.last_word ? word + 1 : e.last_word;
-  const u32 lo = e.words[w0], hi = e.words[w1];
-  const u32 v = __builtin_amdgcn_alignbit(hi, lo, bit & 31);
+  const u32x2 w = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (base_word + (bit >> 5)) * 4, 0, 0);
+  const u32 v = __builtin_amdgcn_alignbit(w.y, w.x, bit);
   return b >= 32 ? v : (v & ((1u << b) - 1u));
 }
 
@@ -225,7 +239,7 @@ __device__ inline u32 bp_extract(const BpView& e, u32 base_word, u32 b, u32 k) {
 // ALIGNED: the wave's lanes evaluate 64 consecutive rows starting at a multiple of 64, so the
 // group is wave-uniform and its index entry is fetched once.
 template <bool ALIGNED>
-__device__ inline u32 bp_get(const BpView& e, u32 i) {
+__device__ __forceinline__ u32 bp_get(const BpView& e, u32 i) {
   if (i >= e.rounded) return lds32(e.tail_off + 4 * ((i - e.rounded) & 31));
   u32 off, hdr;
   if (ALIGNED) {
@@ -242,7 +256,7 @@ __device__ inline u32 bp_get(const BpView& e, u32 i) {
   u32 b = (hdr >> (24 - 8 * m)) & 0xFF;
   b = b > 32 ? 32 : b;
   const u32 before = __builtin_amdgcn_sad_u8((u32)((u64)hdr >> (32 - 8 * m)), 0u, 0u);
-  return bp_extract(e, off + 1 + before, b, k);
+  return bp_extract(make_rsrc(e.base, e.bytes), off + 1 + before, b, k);
 }
 
 // ---- resolved integer pipe -------------------------------------------------------------------
@@ -261,45 +275,47 @@ struct IntEval {
   Tab post_tab[MAX_POST];
 };
 
-__device__ inline IntEval resolve_int(const Ctx& c, u32 pipe_id) {
+__device__ __forceinline__ IntEval resolve_int(const Ctx& c, u32 pipe_id) {
   const Pipe& p = pipe_at(c, pipe_id);
   IntEval e;
-  e.base = p.base;
-  e.count = p.count;
+  e.base = uniform(p.base);
+  e.count = uniform(p.count);
   e.k0 = 0;
   e.bp = BpView{nullptr, 0, 0, 0, 0};
   e.rk = RankView{0, 0};
   e.tab = resolve_tab(c, NONE);
-  switch (p.base) {
-    case B_SEQ: e.tab = resolve_tab(c, p.a[0]); break;
-    case B_ONE: e.k0 = p.a[0]; break;
+  switch (e.base) {
+    case B_SEQ: e.tab = resolve_tab(c, uniform(p.a[0])); break;
+    case B_ONE: e.k0 = uniform(p.a[0]); break;
     case B_BP: e.bp = resolve_bp(c, p); break;
     case B_RLE:
-      e.rk.bits_off = c.table_base + seq_at(c, p.a[0]).off;
-      e.rk.rank_off = c.table_base + seq_at(c, p.a[1]).off;
-      e.tab = resolve_tab(c, p.a[2]);
+      e.rk.bits_off = seq_lds(c, uniform(p.a[0]));
+      e.rk.rank_off = seq_lds(c, uniform(p.a[1]));
+      e.tab = resolve_tab(c, uniform(p.a[2]));
       break;
     case B_FREQ:
-      e.k0 = p.a[0];
-      e.rk.bits_off = c.table_base + seq_at(c, p.a[2]).off;
-      e.rk.rank_off = c.table_base + seq_at(c, p.a[3]).off;
-      e.tab = resolve_tab(c, p.a[4]);
+      e.k0 = uniform(p.a[0]);
+      e.rk.bits_off = seq_lds(c, uniform(p.a[2]));
+      e.rk.rank_off = seq_lds(c, uniform(p.a[3]));
+      e.tab = resolve_tab(c, uniform(p.a[4]));
       break;
     default: break;
   }
-  e.n_post = p.n_post;
+  e.n_post = uniform(p.n_post);
 #pragma unroll
   for (int k = 0; k < MAX_POST; k++) {
-    e.post_type[k] = k < p.n_post ? p.post[k].type : 0;
-    e.post_bias[k] = p.post[k].arg;
-    e.post_tab[k] = resolve_tab(c, (k < p.n_post && p.post[k].type == POST_DICT) ? p.post[k].arg : NONE);
+    const u32 type = k < (int)e.n_post ? uniform(p.post[k].type) : 0;
+    const u32 arg = uniform(p.post[k].arg);
+    e.post_type[k] = type;
+    e.post_bias[k] = arg;
+    e.post_tab[k] = resolve_tab(c, type == POST_DICT ? arg : NONE);
   }
   return e;
 }
 
 // Dictionary gathers and FOR bias adds queued behind the base value
 // (templated/DynamicDictionary.hpp:125-158: dest[i] = dict[codes[i]]; integer/FOR.cpp:62-64).
-__device__ inline u32 apply_posts(const Ctx& c, const IntEval& e, u32 v) {
+__device__ __forceinline__ u32 apply_posts(const Ctx& c, const IntEval& e, u32 v) {
 #pragma unroll
   for (int k = 0; k < MAX_POST; k++) {
     if (k < (int)e.n_post) {
@@ -319,7 +335,7 @@ __device__ inline u32 apply_posts(const Ctx& c, const IntEval& e, u32 v) {
 }
 
 template <u32 BASE, bool ALIGNED>
-__device__ inline u32 eval_int_base(const IntEval& e, u32 i) {
+__device__ __forceinline__ u32 eval_int_base(const IntEval& e, u32 i) {
   if (BASE == B_SEQ) return tab_ld_small(e.tab, i);
   if (BASE == B_ONE) return e.k0;
   if (BASE == B_BP) return bp_get<ALIGNED>(e.bp, i);
@@ -346,7 +362,7 @@ __device__ inline u32 eval_int_base(const IntEval& e, u32 i) {
 }
 
 template <u32 BASE, bool ALIGNED>
-__device__ inline u32 eval_int(const Ctx& c, const IntEval& e, u32 i) {
+__device__ __forceinline__ u32 eval_int(const Ctx& c, const IntEval& e, u32 i) {
   u32 v;
   if (BASE != GEN) {
     v = eval_int_base<BASE, ALIGNED>(e, i);
@@ -374,45 +390,47 @@ struct DblEval {
   IntEval ib;   // B_PSEUDO exponents
 };
 
-__device__ inline DblEval resolve_dbl(const Ctx& c, u32 pipe_id) {
+__device__ __forceinline__ DblEval resolve_dbl(const Ctx& c, u32 pipe_id) {
   const Pipe& p = pipe_at(c, pipe_id);
   DblEval e;
-  e.base = p.base;
-  e.count = p.count;
+  e.base = uniform(p.base);
+  e.count = uniform(p.count);
   e.k0 = e.k1 = 0;
   e.rk = RankView{0, 0};
   e.tab = resolve_tab(c, NONE);
   e.ia.base = e.ib.base = B_ONE;
   e.ia.n_post = e.ib.n_post = 0;
-  switch (p.base) {
-    case B_SEQ: e.tab = resolve_tab(c, p.a[0]); break;
+  const u32 a0 = uniform(p.a[0]), a1 = uniform(p.a[1]), a2 = uniform(p.a[2]), a3 = uniform(p.a[3]),
+            a4 = uniform(p.a[4]), a5 = uniform(p.a[5]);
+  switch (e.base) {
+    case B_SEQ: e.tab = resolve_tab(c, a0); break;
     case B_ONE:
-      e.k0 = p.a[0];
-      e.k1 = p.a[1];
+      e.k0 = a0;
+      e.k1 = a1;
       break;
     case B_RLE:
-      e.rk.bits_off = c.table_base + seq_at(c, p.a[0]).off;
-      e.rk.rank_off = c.table_base + seq_at(c, p.a[1]).off;
-      e.tab = resolve_tab(c, p.a[2]);
+      e.rk.bits_off = seq_lds(c, a0);
+      e.rk.rank_off = seq_lds(c, a1);
+      e.tab = resolve_tab(c, a2);
       break;
     case B_FREQ:
-      e.k0 = p.a[0];
-      e.k1 = p.a[1];
-      e.rk.bits_off = c.table_base + seq_at(c, p.a[2]).off;
-      e.rk.rank_off = c.table_base + seq_at(c, p.a[3]).off;
-      e.tab = resolve_tab(c, p.a[4]);
+      e.k0 = a0;
+      e.k1 = a1;
+      e.rk.bits_off = seq_lds(c, a2);
+      e.rk.rank_off = seq_lds(c, a3);
+      e.tab = resolve_tab(c, a4);
       break;
     case B_DICTD:
-      e.ia = resolve_int(c, p.a[0]);
-      e.tab = resolve_tab(c, p.a[1]);
+      e.ia = resolve_int(c, a0);
+      e.tab = resolve_tab(c, a1);
       break;
     case B_PSEUDO:
-      if (p.a[0] != NONE) e.ia = resolve_int(c, p.a[0]);
-      e.ib = resolve_int(c, p.a[1]);
-      e.tab = resolve_tab(c, p.a[2]);
-      e.rk.bits_off = c.table_base + seq_at(c, p.a[3]).off;
-      e.rk.rank_off = c.table_base + seq_at(c, p.a[4]).off;
-      e.k0 = p.a[5];
+      if (a0 != NONE) e.ia = resolve_int(c, a0);
+      e.ib = resolve_int(c, a1);
+      e.tab = resolve_tab(c, a2);
+      e.rk.bits_off = seq_lds(c, a3);
+      e.rk.rank_off = seq_lds(c, a4);
+      e.k0 = a5;
       break;
     case B_DBP:
       e.ia.base = B_BP;
@@ -425,7 +443,7 @@ __device__ inline DblEval resolve_dbl(const Ctx& c, u32 pipe_id) {
 
 // IA / IB: base kinds of the nested integer pipes when known at compile time, else GEN.
 template <u32 BASE, u32 IA, u32 IB>
-__device__ inline u64 eval_dbl(const Ctx& c, const DblEval& e, u32 i) {
+__device__ __forceinline__ u64 eval_dbl(const Ctx& c, const DblEval& e, u32 i) {
   if (BASE == B_SEQ) return tab_ld64(e.tab, i);
   if (BASE == B_ONE) return ((u64)e.k1 << 32) | e.k0;
   if (BASE == B_RLE) {
@@ -504,87 +522,87 @@ __device__ inline u32 block_exclusive_scan(const Ctx& c, u32 v, u32* total) {
 }
 
 // ---- step: bit-unpack group index ---------------------------------------------------------------
-// One wave per stream. A window is 256 payload words, four consecutive words per lane. Every
-// word is turned into "group length if this word were a header" (1 + the sum of its four width
-// bytes, one byte per word); the chain of real headers is then followed through the window with
-// wave-uniform readlane steps. Windows are fetched four at a time, the next four while the
-// current four are walked. Group start positions collect in a register (lane g%64 keeps group g)
-// and are flushed to LDS every 64 groups; headers are gathered in parallel afterwards.
-struct Window {
-  u32 x0, x1, x2, x3;
-};
-
-__device__ inline Window load_window(const u32* words, u32 W, u32 wb, u32 lane) {
-  Window w;
-  const u32 w0 = wb + 4 * lane;
-  if (w0 + 4 <= W) {
-    uint4 v;
-    __builtin_memcpy(&v, words + w0, 16);
-    w.x0 = v.x, w.x1 = v.y, w.x2 = v.z, w.x3 = v.w;
-  } else {
-    w.x0 = w0 < W ? words[w0] : 0;
-    w.x1 = w0 + 1 < W ? words[w0 + 1] : 0;
-    w.x2 = w0 + 2 < W ? words[w0 + 2] : 0;
-    w.x3 = w0 + 3 < W ? words[w0 + 3] : 0;
-  }
-  return w;
-}
-
-__device__ inline u32 group_lengths(const Window& w) {
+// One wave per stream. The payload is taken in batches of 1024 words, sixteen per lane (four
+// coalesced 16-byte buffer loads), the next batch in flight while the current one is walked.
+// Every word is turned into "group length if this word were a header" (1 + the sum of its four
+// width bytes); the chain of real headers is then followed through the batch (see the loop).
+// Group start positions go to the LDS index; header words are gathered in parallel afterwards.
+__device__ inline u32 group_lengths(const u32x4& w) {
   auto glen = [](u32 x) {
     const u32 s = 1 + __builtin_amdgcn_sad_u8(x, 0u, 0u);
     return s > 255 ? 255u : s;
   };
-  return glen(w.x0) | (glen(w.x1) << 8) | (glen(w.x2) << 16) | (glen(w.x3) << 24);
+  return glen(w.x) | (glen(w.y) << 8) | (glen(w.z) << 16) | (glen(w.w) << 24);
 }
 
-constexpr u32 kWalkBatch = 4;  // windows in flight per batch
+constexpr u32 kWalkBatch = 4;  // 256-word windows per batch (1024 words, 16 per lane)
+
+// "Group length if the word at batch position p were a header", gathered from the lane that
+// holds it: lane (p/4)%64 keeps byte p%4 of window p/256.
+__device__ inline u32 length_at(const u32 (&d)[kWalkBatch], u32 p) {
+  const u32 src_lane = ((p >> 2) & 63) << 2;
+  u32 v = __builtin_amdgcn_ds_bpermute(src_lane, d[0]);
+#pragma unroll
+  for (u32 k = 1; k < kWalkBatch; k++) {
+    const u32 t = __builtin_amdgcn_ds_bpermute(src_lane, d[k]);
+    v = (p >> 8) == k ? t : v;
+  }
+  return (v >> (8 * (p & 3))) & 0xFF;
+}
 
 __device__ void bp_index_wave(const Ctx& c, const Pipe& p) {
   const u32 lane = threadIdx.x & 63;
-  const u32* words = reinterpret_cast<const u32*>(c.src + p.a[0]);
-  const u32 W = p.a[1], rounded = p.a[3], groups = p.a[5];
-  const u32 index_off = c.table_base + seq_at(c, p.a[2]).off;
-  u32 pos = 1, g = 0, mine = 0;
-  Window cur[kWalkBatch], nxt[kWalkBatch];
+  const u8* base = c.src + uniform(p.a[0]);
+  const u32 W = uniform(p.a[1]), rounded = uniform(p.a[3]), groups = uniform(p.a[5]);
+  const u32 index_off = seq_lds(c, uniform(p.a[2]));
+  const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(base, W * 4);
+  const u32* words = reinterpret_cast<const u32*>(base);
+  constexpr u32 kBatchWords = 256 * kWalkBatch;
+  u32 pos = 1, g = 0;
+  u32x4 cur[kWalkBatch], nxt[kWalkBatch];
 #pragma unroll
-  for (u32 k = 0; k < kWalkBatch; k++) cur[k] = load_window(words, W, 256 * k, lane);
-  for (u32 bb = 0; g < groups && bb < W; bb += 256 * kWalkBatch) {
-    const bool more = bb + 256 * kWalkBatch < W;
-    if (more) {
+  for (u32 k = 0; k < kWalkBatch; k++)
+    cur[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (256 * k + 4 * lane) * 4, 0, 0);
+  for (u32 bb = 0; g < groups && bb < W; bb += kBatchWords) {
 #pragma unroll
-      for (u32 k = 0; k < kWalkBatch; k++) nxt[k] = load_window(words, W, bb + 256 * (kWalkBatch + k), lane);
+    for (u32 k = 0; k < kWalkBatch; k++)  // next batch; reads past the payload return 0
+      nxt[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (bb + kBatchWords + 256 * k + 4 * lane) * 4, 0, 0);
+    u32 d[kWalkBatch];
+#pragma unroll
+    for (u32 k = 0; k < kWalkBatch; k++) d[k] = group_lengths(cur[k]);
+    // Follow the header chain through the batch. Each step reads the length D of the group at
+    // `pos` and guesses that the following groups have the same length: lane j checks the word
+    // at pos + j*D. The leading run of lanes that also find length D are real headers (lane 0
+    // is one by construction, and a confirmed lane j makes the guess of lane j+1 exact), so a
+    // stretch of equally wide groups costs one step; a width change ends the run and the next
+    // step starts from the first unconfirmed position.
+    while (pos < bb + kBatchWords && g < groups) {
+      const u32 rel = pos - bb;
+      const u32 D = uniform(length_at(d, rel));
+      const u32 pj = rel + lane * D;
+      const bool inside = pj < kBatchWords;
+      const u32 dj = length_at(d, inside ? pj : rel);
+      const u64 ok = __ballot(inside && dj == D);
+      u32 m = (u32)__builtin_ctzll(~ok | (1ull << 63)) ;
+      m = m == 63 && (ok >> 63) ? 64 : m;
+      m = m < groups - g ? m : groups - g;
+      if (lane < m) lds_st32(index_off + 8 * (g + lane), bb + pj);
+      g = uniform(g + m);
+      pos = uniform(pos + m * D);
     }
 #pragma unroll
-    for (u32 k = 0; k < kWalkBatch; k++) {
-      const u32 wb = bb + 256 * k;
-      const u32 d = group_lengths(cur[k]);
-      while (pos < wb + 256 && g < groups) {
-        const u32 rel = pos - wb;
-        const u32 dv = __builtin_amdgcn_readlane(d, rel >> 2);
-        mine = lane == (g & 63) ? pos : mine;
-        pos += (dv >> (8 * (rel & 3))) & 0xFF;
-        g++;
-        if ((g & 63) == 0) lds_st32(index_off + 8 * (g - 64 + lane), mine);
-      }
-    }
-    if (more) {
-#pragma unroll
-      for (u32 k = 0; k < kWalkBatch; k++) cur[k] = nxt[k];
-    }
+    for (u32 k = 0; k < kWalkBatch; k++) cur[k] = nxt[k];
   }
   u32 bad = g < groups;  // the stream ended before all groups were found
   const u32 found = g;
-  if ((found & 63) && lane < (found & 63)) lds_st32(index_off + 8 * ((found & ~63u) + lane), mine);
   if (pos > W) {
     bad = 1;
     pos = W;
   }
   // parallel pass: fetch and validate the header word of every group
   for (u32 gg = lane; gg < groups; gg += 64) {
-    u32 gp = gg < found ? lds32(index_off + 8 * gg) : 0;
-    gp = gp < W ? gp : (W ? W - 1 : 0);
-    const u32 hv = W ? words[gp] : 0;
+    const u32 gp = gg < found ? lds32(index_off + 8 * gg) : 0;
+    const u32 hv = __builtin_amdgcn_raw_buffer_load_b32(rsrc, gp * 4, 0, 0);
     // every width byte must be <= 32
     if ((hv & 0xC0C0C0C0u) || ((hv + 0x5F5F5F5Fu) & 0x80808080u)) bad = 1;
     lds_st64(index_off + 8 * gg, ((u64)hv << 32) | gp);
@@ -593,9 +611,11 @@ __device__ void bp_index_wave(const Ctx& c, const Pipe& p) {
   if (bad) raise(c, ST_BP_HEADER);
 
   // VariableByte tail (fewer than 32 values): 7 bits per byte, low group first, top bit ends a value.
-  if (p.a[4] != NONE) {
-    const u32 tail_off = c.table_base + seq_at(c, p.a[4]).off;
-    const u32 stream_values = p.base == B_DBP ? 2 * p.count : p.count;
+  const u32 tail_seq = uniform(p.a[4]);
+  if (tail_seq != NONE) {
+    const u32 tail_off = seq_lds(c, tail_seq);
+    const u32 count = uniform(p.count);
+    const u32 stream_values = uniform(p.base) == B_DBP ? 2 * count : count;
     const u32 expect = stream_values - rounded;
     const u32 tail_words = W - pos < 64 ? W - pos : 64;
     const u32 tw = lane < tail_words ? words[pos + lane] : 0;
@@ -620,7 +640,7 @@ __device__ void bp_index_wave(const Ctx& c, const Pipe& p) {
 constexpr u32 kUnroll = 4;
 
 template <u32 BASE>
-__device__ void mat_int(const Ctx& c, const IntEval& e, const Tab& out, u32 count) {
+__device__ __forceinline__ void mat_int(const Ctx& c, const IntEval& e, const Tab& out, u32 count) {
   const u32 tid = threadIdx.x;
   for (u32 base = 0; base < count; base += kBlockThreads * kUnroll) {
     u32 v[kUnroll];
@@ -640,11 +660,12 @@ __device__ void mat_int(const Ctx& c, const IntEval& e, const Tab& out, u32 coun
 // Root loop for a bit-packed base: every wave takes whole 128-value groups, lane l produces
 // values l and l+64 of the group (miniblocks l/32 and 2+l/32), so the header and the miniblock
 // offsets are wave-uniform and a group's 128 values are stored as two contiguous 256-byte rows.
-constexpr u32 kGroupsPerIter = 2;
+constexpr u32 kGroupsPerIter = 4;
 
-__device__ void mat_int_bp(const Ctx& c, const IntEval& e, const Tab& out, u32 count) {
-  const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+__device__ __forceinline__ void mat_int_bp(const Ctx& c, const IntEval& e, const Tab& out, u32 count) {
+  const u32 lane = threadIdx.x & 63, wave = uniform(threadIdx.x >> 6);
   const BpView& bp = e.bp;
+  const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(bp.base, bp.bytes);
   const u32 groups = (bp.rounded + btrfmt::FBP_GROUP - 1) / btrfmt::FBP_GROUP;
   const u32 k = lane & 31;
   const bool upper = lane >= 32;
@@ -664,8 +685,13 @@ __device__ void mat_int_bp(const Ctx& c, const IntEval& e, const Tab& out, u32 c
       // miniblocks 0/1 (value lane) and 2/3 (value lane + 64)
       const u32 w_lo = upper ? first + b0 : first;
       const u32 w_hi = upper ? first + b0 + b1 + b2 : first + b0 + b1;
-      v[j][0] = apply_posts(c, e, bp_extract(bp, w_lo, upper ? b1 : b0, k));
-      v[j][1] = apply_posts(c, e, bp_extract(bp, w_hi, upper ? b3 : b2, k));
+      v[j][0] = bp_extract(rsrc, w_lo, upper ? b1 : b0, k);
+      v[j][1] = bp_extract(rsrc, w_hi, upper ? b3 : b2, k);
+    }
+#pragma unroll
+    for (u32 j = 0; j < kGroupsPerIter; j++) {
+      v[j][0] = apply_posts(c, e, v[j][0]);
+      v[j][1] = apply_posts(c, e, v[j][1]);
     }
 #pragma unroll
     for (u32 j = 0; j < kGroupsPerIter; j++) {
@@ -681,7 +707,7 @@ __device__ void mat_int_bp(const Ctx& c, const IntEval& e, const Tab& out, u32 c
 }
 
 template <u32 BASE, u32 IA, u32 IB>
-__device__ void mat_dbl(const Ctx& c, const DblEval& e, const Tab& out, u32 count) {
+__device__ __forceinline__ void mat_dbl(const Ctx& c, const DblEval& e, const Tab& out, u32 count) {
   const u32 tid = threadIdx.x;
   for (u32 base = 0; base < count; base += kBlockThreads * kUnroll) {
     u64 v[kUnroll];
@@ -699,9 +725,9 @@ __device__ void mat_dbl(const Ctx& c, const DblEval& e, const Tab& out, u32 coun
 }
 
 template <bool DOUBLE_KERNEL>
-__device__ void materialize(const Ctx& c, u32 pipe_id, u32 seq_id) {
-  const u32 count = pipe_at(c, pipe_id).count;
-  const bool is_double = pipe_at(c, pipe_id).is_double;
+__device__ __forceinline__ void materialize(const Ctx& c, u32 pipe_id, u32 seq_id) {
+  const u32 count = uniform(pipe_at(c, pipe_id).count);
+  const bool is_double = uniform(pipe_at(c, pipe_id).is_double) != 0;
   const Tab out = resolve_tab(c, seq_id);
   if (count == 0) return;
   if (!is_double) {
@@ -745,16 +771,16 @@ __device__ inline void bitmap_or(u32 bits_off, u32 row) {
 }
 
 __device__ void bitmap_clear(const Ctx& c, const Step& s) {
-  const Seq bm = seq_at(c, s.a[1]);
-  const u32 off = c.table_base + bm.off;
-  for (u32 w = threadIdx.x; w < bm.count * 2; w += kBlockThreads) lds_st32(off + 4 * w, 0);
+  const Seq& bm = seq_at(c, uniform(s.a[1]));
+  const u32 off = c.table_base + uniform(bm.off), words = uniform(bm.count) * 2;
+  for (u32 w = threadIdx.x; w < words; w += kBlockThreads) lds_st32(off + 4 * w, 0);
 }
 
 // Members of one CRoaring container (or of the whole bitmap for the u32-array form) -> bits.
 __device__ void bitmap_set(const Ctx& c, const Step& s) {
-  const u8* src = c.src + s.a[0];
-  const u32 bits_off = c.table_base + seq_at(c, s.a[1]).off;
-  const u32 count = s.a[2], first = s.a[3], nbits = s.a[4], kind = s.a[5];
+  const u8* src = c.src + uniform(s.a[0]);
+  const u32 bits_off = seq_lds(c, uniform(s.a[1]));
+  const u32 count = uniform(s.a[2]), first = uniform(s.a[3]), nbits = uniform(s.a[4]), kind = uniform(s.a[5]);
   u32 bad = 0;
   for (u32 k = threadIdx.x; k < count; k += kBlockThreads) {
     switch (kind) {
@@ -810,9 +836,9 @@ __device__ void bitmap_set(const Ctx& c, const Step& s) {
 // Run lengths -> run starts (exclusive scan) -> one start flag per run (templated/RLE.hpp:164-191
 // expands runs back to back; the start of run r is the sum of the lengths before it).
 __device__ void bitmap_starts(const Ctx& c, const Step& s) {
-  const Tab len = resolve_tab(c, s.a[0]);
-  const u32 bits_off = c.table_base + seq_at(c, s.a[1]).off;
-  const u32 nbits = s.a[3], runs = s.a[4];
+  const Tab len = resolve_tab(c, uniform(s.a[0]));
+  const u32 bits_off = seq_lds(c, uniform(s.a[1]));
+  const u32 nbits = uniform(s.a[3]), runs = uniform(s.a[4]);
   u32 carry = 0, bad = 0;
   for (u32 base = 0; base < runs; base += kBlockThreads) {
     const u32 r = base + threadIdx.x;
@@ -834,9 +860,9 @@ __device__ void bitmap_starts(const Ctx& c, const Step& s) {
 
 // bit i = (pipe[i] == value); each wave writes the 64-bit ballot of its 64 consecutive rows.
 __device__ void bitmap_eq(const Ctx& c, const Step& s) {
-  const IntEval e = resolve_int(c, s.a[0]);
-  const u32 bits_off = c.table_base + seq_at(c, s.a[1]).off;
-  const u32 nbits = s.a[3], value = s.a[4];
+  const IntEval e = resolve_int(c, uniform(s.a[0]));
+  const u32 bits_off = seq_lds(c, uniform(s.a[1]));
+  const u32 nbits = uniform(s.a[3]), value = uniform(s.a[4]);
   for (u32 base = 0; base < nbits; base += kBlockThreads) {
     const u32 i = base + threadIdx.x;
     const u32 ii = i < nbits ? i : nbits - 1;
@@ -847,25 +873,26 @@ __device__ void bitmap_eq(const Ctx& c, const Step& s) {
 }
 
 __device__ void bitmap_rank(const Ctx& c, const Step& s) {
-  const Seq bm = seq_at(c, s.a[1]);
-  const u32 bits_off = c.table_base + bm.off;
-  const u32 rank_off = c.table_base + seq_at(c, s.a[2]).off;
+  const Seq& bm = seq_at(c, uniform(s.a[1]));
+  const u32 bits_off = c.table_base + uniform(bm.off), words = uniform(bm.count);
+  const u32 rank_off = seq_lds(c, uniform(s.a[2]));
   u32 carry = 0;
-  for (u32 base = 0; base < bm.count; base += kBlockThreads) {
+  for (u32 base = 0; base < words; base += kBlockThreads) {
     const u32 w = base + threadIdx.x;
-    const u32 pc = w < bm.count ? __popcll(lds64(bits_off + 8 * w)) : 0;
+    const u32 pc = w < words ? __popcll(lds64(bits_off + 8 * w)) : 0;
     u32 total;
     const u32 ex = carry + block_exclusive_scan(c, pc, &total);
-    if (w < bm.count) lds_st32(rank_off + 4 * w, ex);
+    if (w < words) lds_st32(rank_off + 4 * w, ex);
     carry += total;
   }
-  if (s.a[4] != NONE && carry != s.a[4] && threadIdx.x == 0) raise(c, s.a[5]);
+  const u32 expect = uniform(s.a[4]);
+  if (expect != NONE && carry != expect && threadIdx.x == 0) raise(c, uniform(s.a[5]));
 }
 
 // extern/RoaringBitmap.cpp:32-53: one byte per row, 1 = valid.
 __device__ void write_nullmap(const Ctx& c, const Step& s) {
-  const u32 type = s.a[0], n = s.a[3];
-  const u32 bits_off = s.a[1] == NONE ? 0 : c.table_base + seq_at(c, s.a[1]).off;
+  const u32 type = uniform(s.a[0]), n = uniform(s.a[3]);
+  const u32 bits_off = uniform(s.a[1]) == NONE ? 0 : seq_lds(c, uniform(s.a[1]));
   for (u32 i = threadIdx.x; i < n; i += kBlockThreads) {
     u8 v;
     if (type == btrfmt::NM_ALLONES) {
@@ -892,7 +919,11 @@ __device__ inline void decode_block(const WorkItem* __restrict__ items, const u3
     if (tid == 0) status[item] = 0;  // later raise() calls are ordered behind the barrier
   }
   __syncthreads();
-  const ProgramHeader hdr = *reinterpret_cast<const ProgramHeader*>(lds_raw);
+  ProgramHeader hdr = *reinterpret_cast<const ProgramHeader*>(lds_raw);
+  hdr.n_steps = uniform(hdr.n_steps);
+  hdr.n_bp_steps = uniform(hdr.n_bp_steps);
+  hdr.n_pipes = uniform(hdr.n_pipes);
+  hdr.table_base = uniform(hdr.table_base);
   Ctx c;
   c.src = reinterpret_cast<const u8*>(it.src);
   c.dst = reinterpret_cast<u8*>(it.dst);
@@ -906,14 +937,16 @@ __device__ inline void decode_block(const WorkItem* __restrict__ items, const u3
   c.red_off = hdr.table_base - 64;
 
   // bit-unpack indexes: one stream per wave, streams in parallel
-  for (u32 s = tid >> 6; s < hdr.n_bp_steps; s += kBlockThreads / 64)
-    bp_index_wave(c, pipe_at(c, step_at(c, s).a[0]));
+  if (!(it.debug_flags & 1))
+    for (u32 s = uniform(tid >> 6); s < hdr.n_bp_steps; s += kBlockThreads / 64)
+      bp_index_wave(c, pipe_at(c, uniform(step_at(c, s).a[0])));
   __syncthreads();
 
   for (u32 s = hdr.n_bp_steps; s < hdr.n_steps; s++) {
-    const Step st = step_at(c, s);
-    switch (st.kind) {
-      case S_MATERIALIZE: materialize<DOUBLE_KERNEL>(c, st.a[0], st.a[1]); break;
+    const Step& st = step_at(c, s);
+    if ((it.debug_flags & 2) && s + 1 == hdr.n_steps) break;
+    switch (uniform(st.kind)) {
+      case S_MATERIALIZE: materialize<DOUBLE_KERNEL>(c, uniform(st.a[0]), uniform(st.a[1])); break;
       case S_BITMAP_CLEAR: bitmap_clear(c, st); break;
       case S_BITMAP_SET: bitmap_set(c, st); break;
       case S_BITMAP_STARTS: bitmap_starts(c, st); break;

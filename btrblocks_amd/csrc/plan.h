@@ -112,6 +112,8 @@ struct WorkItem {
   uint32_t prog_bytes;
   uint32_t tuple_count;
   uint32_t src_bytes;
+  uint32_t debug_flags;  // diagnostics only (BTR_DEBUG_FLAGS): 1 = skip index walks, 2 = skip the root step
+  uint32_t pad;
 };
 
 // Device status bits, one word per work item.
