@@ -33,6 +33,9 @@ COLUMNS = {
     "dict": ("int_dict", "dict(bp)", 2),
     "for": ("int_for", "for(bp)", 3),
     "pseudodecimal": ("double_decimal", "pseudodecimal(bp,bp,uncompressed)", 4),
+    # engine ceilings: a pure fill (ONE_VALUE) and a pure copy (UNCOMPRESSED)
+    "onevalue": ("int_constant", "onevalue", 5),
+    "uncompressed": ("int_for", "uncompressed", 6),
 }
 
 

@@ -550,74 +550,106 @@ __device__ inline u32 length_at(const u32 (&d)[kWalkBatch], u32 p) {
   return (v >> (8 * (p & 3))) & 0xFF;
 }
 
-__device__ void bp_index_wave(const Ctx& c, const Pipe& p) {
-  const u32 lane = threadIdx.x & 63;
-  const u8* base = c.src + uniform(p.a[0]);
-  const u32 W = uniform(p.a[1]), rounded = uniform(p.a[3]), groups = uniform(p.a[5]);
-  const u32 index_off = seq_lds(c, uniform(p.a[2]));
-  const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(base, W * 4);
-  const u32* words = reinterpret_cast<const u32*>(base);
-  constexpr u32 kBatchWords = 256 * kWalkBatch;
-  u32 pos = 1, g = 0;
-  u32x4 cur[kWalkBatch], nxt[kWalkBatch];
-#pragma unroll
-  for (u32 k = 0; k < kWalkBatch; k++)
-    cur[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (256 * k + 4 * lane) * 4, 0, 0);
-  for (u32 bb = 0; g < groups && bb < W; bb += kBatchWords) {
-#pragma unroll
-    for (u32 k = 0; k < kWalkBatch; k++)  // next batch; reads past the payload return 0
-      nxt[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (bb + kBatchWords + 256 * k + 4 * lane) * 4, 0, 0);
-    u32 d[kWalkBatch];
-#pragma unroll
-    for (u32 k = 0; k < kWalkBatch; k++) d[k] = group_lengths(cur[k]);
-    // Follow the header chain through the batch. Each step reads the length D of the group at
-    // `pos` and guesses that the following groups have the same length: lane j checks the word
-    // at pos + j*D. The leading run of lanes that also find length D are real headers (lane 0
-    // is one by construction, and a confirmed lane j makes the guess of lane j+1 exact), so a
-    // stretch of equally wide groups costs one step; a width change ends the run and the next
-    // step starts from the first unconfirmed position.
-    while (pos < bb + kBatchWords && g < groups) {
-      const u32 rel = pos - bb;
-      const u32 D = uniform(length_at(d, rel));
-      const u32 pj = rel + lane * D;
-      const bool inside = pj < kBatchWords;
-      const u32 dj = length_at(d, inside ? pj : rel);
-      const u64 ok = __ballot(inside && dj == D);
-      u32 m = (u32)__builtin_ctzll(~ok | (1ull << 63)) ;
-      m = m == 63 && (ok >> 63) ? 64 : m;
-      m = m < groups - g ? m : groups - g;
-      if (lane < m) lds_st32(index_off + 8 * (g + lane), bb + pj);
-      g = uniform(g + m);
-      pos = uniform(pos + m * D);
-    }
-#pragma unroll
-    for (u32 k = 0; k < kWalkBatch; k++) cur[k] = nxt[k];
-  }
-  u32 bad = g < groups;  // the stream ended before all groups were found
-  const u32 found = g;
-  if (pos > W) {
-    bad = 1;
-    pos = W;
-  }
-  // parallel pass: fetch and validate the header word of every group
-  for (u32 gg = lane; gg < groups; gg += 64) {
-    const u32 gp = gg < found ? lds32(index_off + 8 * gg) : 0;
-    const u32 hv = __builtin_amdgcn_raw_buffer_load_b32(rsrc, gp * 4, 0, 0);
-    // every width byte must be <= 32
-    if ((hv & 0xC0C0C0C0u) || ((hv + 0x5F5F5F5Fu) & 0x80808080u)) bad = 1;
-    lds_st64(index_off + 8 * gg, ((u64)hv << 32) | gp);
-  }
-  if (lane == 0) lds_st64(index_off + 8 * groups, (u64)pos);
-  if (bad) raise(c, ST_BP_HEADER);
+// Resumable walk state, kept in the registers of the walking wave.
+struct Walker {
+  const u8* base;
+  u32 W, rounded, groups, index_off;
+  u32 pos, g, bb;  // next header position, groups found, first word of the current batch
+  u32 gathered;    // groups whose header word has been fetched into the index
+  u32 bad;
+  u32 d[kWalkBatch];      // packed group lengths of the current batch
+  u32x4 nxt[kWalkBatch];  // next batch, in flight
+};
+constexpr u32 kBatchWords = 256 * kWalkBatch;
 
-  // VariableByte tail (fewer than 32 values): 7 bits per byte, low group first, top bit ends a value.
+__device__ __forceinline__ u32x4 load_window(__amdgpu_buffer_rsrc_t rsrc, u32 first_word, u32 lane) {
+  return __builtin_amdgcn_raw_buffer_load_b128(rsrc, (first_word + 4 * lane) * 4, 0, 0);  // past the end: 0
+}
+
+__device__ __forceinline__ void walker_init(Walker& w, const Ctx& c, const Pipe& p) {
+  const u32 lane = threadIdx.x & 63;
+  w.base = c.src + uniform(p.a[0]);
+  w.W = uniform(p.a[1]);
+  w.rounded = uniform(p.a[3]);
+  w.groups = uniform(p.a[5]);
+  w.index_off = seq_lds(c, uniform(p.a[2]));
+  const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(w.base, w.W * 4);
+  u32x4 cur[kWalkBatch];
+#pragma unroll
+  for (u32 k = 0; k < kWalkBatch; k++) cur[k] = load_window(rsrc, 256 * k, lane);
+#pragma unroll
+  for (u32 k = 0; k < kWalkBatch; k++) w.nxt[k] = load_window(rsrc, kBatchWords + 256 * k, lane);
+#pragma unroll
+  for (u32 k = 0; k < kWalkBatch; k++) w.d[k] = group_lengths(cur[k]);
+  w.pos = 1;
+  w.g = w.bb = w.gathered = w.bad = 0;
+}
+
+// Finds group starts until `until` groups are known (or the stream ends) and completes their
+// index entries {word offset, header}.
+__device__ __forceinline__ void walker_advance(Walker& w, u32 until) {
+  const u32 lane = threadIdx.x & 63;
+  const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(w.base, w.W * 4);
+  until = until < w.groups ? until : w.groups;
+  while (w.g < until) {
+    if (w.pos >= w.bb + kBatchWords) {  // move to the next batch
+      if (w.bb + kBatchWords >= w.W) break;
+      w.bb += kBatchWords;
+#pragma unroll
+      for (u32 k = 0; k < kWalkBatch; k++) w.d[k] = group_lengths(w.nxt[k]);
+#pragma unroll
+      for (u32 k = 0; k < kWalkBatch; k++) w.nxt[k] = load_window(rsrc, w.bb + kBatchWords + 256 * k, lane);
+      continue;
+    }
+    // One step: read the length D of the group at `pos` and guess that the following groups
+    // have the same length: lane j checks the word at pos + j*D. The leading run of lanes that
+    // also find length D are real headers (lane 0 is one by construction, and a confirmed lane j
+    // makes the guess of lane j+1 exact), so a stretch of equally wide groups costs one step; a
+    // width change ends the run and the next step starts from the first unconfirmed position.
+    const u32 rel = w.pos - w.bb;
+    const u32 D = uniform(length_at(w.d, rel));
+    const u32 pj = rel + lane * D;
+    const bool inside = pj < kBatchWords;
+    const u32 dj = length_at(w.d, inside ? pj : rel);
+    const u64 ok = __ballot(inside && dj == D);
+    u32 m = (u32)__builtin_ctzll(~ok | (1ull << 63));
+    m = m == 63 && (ok >> 63) ? 64 : m;
+    m = m < until - w.g ? m : until - w.g;
+    if (lane < m) lds_st32(w.index_off + 8 * (w.g + lane), w.bb + pj);
+    w.g = uniform(w.g + m);
+    w.pos = uniform(w.pos + m * D);
+  }
+  // fetch and validate the header word of every new group (every width byte must be <= 32)
+  for (u32 gg = w.gathered + lane; gg < w.g; gg += 64) {
+    const u32 gp = lds32(w.index_off + 8 * gg);
+    const u32 hv = __builtin_amdgcn_raw_buffer_load_b32(rsrc, gp * 4, 0, 0);
+    if ((hv & 0xC0C0C0C0u) || ((hv + 0x5F5F5F5Fu) & 0x80808080u)) w.bad = 1;
+    lds_st32(w.index_off + 8 * gg + 4, hv);
+  }
+  w.gathered = w.g;
+}
+
+// After the last group: flags, the end-of-packing sentinel and the VariableByte tail (fewer
+// than 32 values: 7 bits per byte, low group first, a set top bit ends a value).
+__device__ __forceinline__ void walker_finish(Walker& w, const Ctx& c, const Pipe& p) {
+  const u32 lane = threadIdx.x & 63;
+  u32 bad = w.bad | (w.g < w.groups);  // the stream ended before all groups were found
+  u32 pos = w.pos;
+  if (pos > w.W) {
+    bad = 1;
+    pos = w.W;
+  }
+  for (u32 gg = w.g + lane; gg < w.groups; gg += 64) lds_st64(w.index_off + 8 * gg, 0);
+  if (lane == 0) lds_st64(w.index_off + 8 * w.groups, (u64)pos);
+  if (bad) raise(c, ST_BP_HEADER);
   const u32 tail_seq = uniform(p.a[4]);
   if (tail_seq != NONE) {
+    const u32* words = reinterpret_cast<const u32*>(w.base);
     const u32 tail_off = seq_lds(c, tail_seq);
     const u32 count = uniform(p.count);
     const u32 stream_values = uniform(p.base) == B_DBP ? 2 * count : count;
-    const u32 expect = stream_values - rounded;
-    const u32 tail_words = W - pos < 64 ? W - pos : 64;
+    const u32 expect = stream_values - w.rounded;
+    const u32 tail_words = w.W - pos < 64 ? w.W - pos : 64;
     const u32 tw = lane < tail_words ? words[pos + lane] : 0;
     u32 v = 0, shift = 0, produced = 0;
     for (u32 bi = 0; bi < tail_words * 4; bi++) {
@@ -634,6 +666,13 @@ __device__ void bp_index_wave(const Ctx& c, const Pipe& p) {
     }
     if (produced != expect && lane == 0) raise(c, ST_BP_TAIL);
   }
+}
+
+__device__ void bp_index_wave(const Ctx& c, const Pipe& p) {
+  Walker w;
+  walker_init(w, c, p);
+  walker_advance(w, w.groups);
+  walker_finish(w, c, p);
 }
 
 // ---- step: materialize a pipe into a sequence ----------------------------------------------------
@@ -662,18 +701,19 @@ __device__ __forceinline__ void mat_int(const Ctx& c, const IntEval& e, const Ta
 // offsets are wave-uniform and a group's 128 values are stored as two contiguous 256-byte rows.
 constexpr u32 kGroupsPerIter = 4;
 
-__device__ __forceinline__ void mat_int_bp(const Ctx& c, const IntEval& e, const Tab& out, u32 count) {
+// Groups [g_lo, g_hi) of a bit-packed root: every wave takes whole 128-value groups.
+__device__ __forceinline__ void eval_bp_groups(const Ctx& c, const IntEval& e, const Tab& out, u32 g_lo,
+                                               u32 g_hi) {
   const u32 lane = threadIdx.x & 63, wave = uniform(threadIdx.x >> 6);
   const BpView& bp = e.bp;
   const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(bp.base, bp.bytes);
-  const u32 groups = (bp.rounded + btrfmt::FBP_GROUP - 1) / btrfmt::FBP_GROUP;
   const u32 k = lane & 31;
   const bool upper = lane >= 32;
-  for (u32 g0 = wave * kGroupsPerIter; g0 < groups; g0 += (kBlockThreads / 64) * kGroupsPerIter) {
+  for (u32 g0 = g_lo + wave * kGroupsPerIter; g0 < g_hi; g0 += (kBlockThreads / 64) * kGroupsPerIter) {
     u32 v[kGroupsPerIter][2];
 #pragma unroll
     for (u32 j = 0; j < kGroupsPerIter; j++) {
-      const u32 g = g0 + j < groups ? g0 + j : groups - 1;
+      const u32 g = g0 + j < g_hi ? g0 + j : g_hi - 1;
       const u64 ih = lds64(bp.index_off + 8 * g);
       const u32 off = uniform((u32)ih), hdr = uniform((u32)(ih >> 32));
       u32 b0 = hdr >> 24, b1 = (hdr >> 16) & 0xFF, b2 = (hdr >> 8) & 0xFF, b3 = hdr & 0xFF;
@@ -696,14 +736,188 @@ __device__ __forceinline__ void mat_int_bp(const Ctx& c, const IntEval& e, const
 #pragma unroll
     for (u32 j = 0; j < kGroupsPerIter; j++) {
       const u32 i = (g0 + j) * btrfmt::FBP_GROUP + lane;
-      if (g0 + j < groups) {
+      if (g0 + j < g_hi) {
         if (i < bp.rounded) tab_st32(out, i, v[j][0]);
         if (i + 64 < bp.rounded) tab_st32(out, i + 64, v[j][1]);
       }
     }
   }
+}
+
+__device__ __forceinline__ void eval_bp_tail(const Ctx& c, const IntEval& e, const Tab& out, u32 count) {
+  const BpView& bp = e.bp;
   for (u32 i = bp.rounded + threadIdx.x; i < count; i += kBlockThreads)
     tab_st32(out, i, apply_posts(c, e, lds32(bp.tail_off + 4 * ((i - bp.rounded) & 31))));
+}
+
+__device__ __forceinline__ void mat_int_bp(const Ctx& c, const IntEval& e, const Tab& out, u32 count) {
+  eval_bp_groups(c, e, out, 0, (e.bp.rounded + btrfmt::FBP_GROUP - 1) / btrfmt::FBP_GROUP);
+  eval_bp_tail(c, e, out, count);
+}
+
+// ---- root step over a bit-packed stream, payload staged through an LDS ring ------------------------
+// The compressed stream is read from HBM exactly once, by 16-byte-per-lane direct-to-LDS buffer
+// loads (1 KiB per wave instruction), and everything else works out of LDS:
+//   wave 3 (loader)  keeps kRingAhead batches of 1024 payload words in flight into a ring of
+//                    kRingBatches batches;
+//   wave 0 (walker)  follows the group-header chain through the batch that has landed and writes
+//                    {word offset, header} per group into the index;
+//   waves 0-2        unpack the groups found in that batch from the ring and store the rows.
+// Two workgroup barriers per batch: A "batch t+1 has landed" (a group that starts in batch t may
+// run into batch t+1), B "the groups of batch t are indexed".
+constexpr u32 kRingBatches = 4;                 // power of two
+constexpr u32 kRingAhead = 3;                   // batches issued ahead of the one being walked
+constexpr u32 kRingWords = kRingBatches * kBatchWords;
+constexpr u32 kRingBytes = kRingWords * 4;
+
+__device__ __forceinline__ void barrier_lds() {  // LDS writes of this wave visible, then barrier
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
+__device__ __forceinline__ u32 ring_word(u32 ring_off, u32 w) { return lds32(ring_off + ((w & (kRingWords - 1)) << 2)); }
+
+__device__ __forceinline__ u32 ring_extract(u32 ring_off, u32 base_word, u32 b, u32 k) {
+  const u32 bit = k * b;
+  const u32 w = base_word + (bit >> 5);
+  const u32 lo = ring_word(ring_off, w), hi = ring_word(ring_off, w + 1);
+  const u32 v = __builtin_amdgcn_alignbit(hi, lo, bit);
+  return b >= 32 ? v : (v & ((1u << b) - 1u));
+}
+
+constexpr u32 kRingGroupsPerIter = 2;
+constexpr u32 kRingWorkers = 3;
+
+// Groups [g_lo, g_hi) unpacked from the ring by waves 0..2; lane l produces values l and l+64.
+__device__ __forceinline__ void ring_eval_groups(const Ctx& c, const IntEval& e, const Tab& out, u32 ring_off,
+                                                 u32 g_lo, u32 g_hi, u32 wave) {
+  const u32 lane = threadIdx.x & 63;
+  const BpView& bp = e.bp;
+  const u32 k = lane & 31;
+  const bool upper = lane >= 32;
+  for (u32 g0 = g_lo + wave * kRingGroupsPerIter; g0 < g_hi; g0 += kRingWorkers * kRingGroupsPerIter) {
+    u32 v[kRingGroupsPerIter][2];
+#pragma unroll
+    for (u32 j = 0; j < kRingGroupsPerIter; j++) {
+      const u32 g = g0 + j < g_hi ? g0 + j : g_hi - 1;
+      const u64 ih = lds64(bp.index_off + 8 * g);
+      const u32 off = uniform((u32)ih), hdr = uniform((u32)(ih >> 32));
+      u32 b0 = hdr >> 24, b1 = (hdr >> 16) & 0xFF, b2 = (hdr >> 8) & 0xFF, b3 = hdr & 0xFF;
+      b0 = b0 > 32 ? 32 : b0;
+      b1 = b1 > 32 ? 32 : b1;
+      b2 = b2 > 32 ? 32 : b2;
+      b3 = b3 > 32 ? 32 : b3;
+      const u32 first = off + 1;
+      const u32 w_lo = upper ? first + b0 : first;
+      const u32 w_hi = upper ? first + b0 + b1 + b2 : first + b0 + b1;
+      v[j][0] = ring_extract(ring_off, w_lo, upper ? b1 : b0, k);
+      v[j][1] = ring_extract(ring_off, w_hi, upper ? b3 : b2, k);
+    }
+#pragma unroll
+    for (u32 j = 0; j < kRingGroupsPerIter; j++) {
+      v[j][0] = apply_posts(c, e, v[j][0]);
+      v[j][1] = apply_posts(c, e, v[j][1]);
+    }
+#pragma unroll
+    for (u32 j = 0; j < kRingGroupsPerIter; j++) {
+      const u32 i = (g0 + j) * btrfmt::FBP_GROUP + lane;
+      if (g0 + j < g_hi) {
+        if (i < bp.rounded) tab_st32(out, i, v[j][0]);
+        if (i + 64 < bp.rounded) tab_st32(out, i + 64, v[j][1]);
+      }
+    }
+  }
+}
+
+__device__ void stream_int_bp(const Ctx& c, u32 pipe_id, u32 seq_id, u32 ring_seq) {
+  const Pipe& p = pipe_at(c, pipe_id);
+  const IntEval e = resolve_int(c, pipe_id);
+  const Tab out = resolve_tab(c, seq_id);
+  const u32 ring_off = seq_lds(c, ring_seq);
+  const u32 lane = threadIdx.x & 63, wave = uniform(threadIdx.x >> 6);
+  const u32 W = uniform(p.a[1]), groups = uniform(p.a[5]);
+  const u32 index_off = e.bp.index_off;
+  const u32 batches = (W + kBatchWords - 1) / kBatchWords;
+  const u32 found_off = c.red_off + 32;  // LDS word: groups indexed so far
+
+  if (wave == kRingWorkers) {
+    // ---- loader
+    const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(e.bp.base, e.bp.bytes);
+    auto issue = [&](u32 t) {
+      if (t >= batches) return;
+      const u32 slot = ring_off + (t & (kRingBatches - 1)) * (kBatchWords * 4);
+#pragma unroll
+      for (u32 k = 0; k < kWalkBatch; k++)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(
+            rsrc, (__attribute__((address_space(3))) void*)(lds_raw + slot + k * 1024), 16,
+            (t * kBatchWords + 256 * k + 4 * lane) * 4, 0, 0, 0);
+    };
+    for (u32 t = 0; t < kRingAhead; t++) issue(t);
+    for (u32 t = 0; t < batches; t++) {
+      // batches t and t+1 must have landed; at most one younger batch (t+2) may stay in flight
+      if (t + 2 < batches)
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();  // A_t
+      issue(t + kRingAhead);
+      __builtin_amdgcn_s_barrier();  // B_t
+    }
+  } else {
+    // ---- walker (wave 0) and unpackers (waves 0..2)
+    u32 pos = 1, g = 0, bad = 0;
+    for (u32 t = 0; t < batches; t++) {
+      const u32 g_before = g;
+      __builtin_amdgcn_s_barrier();  // A_t
+      asm volatile("" ::: "memory");
+      if (wave == 0) {
+        const u32 bb = t * kBatchWords;
+        const u32 slot = ring_off + (t & (kRingBatches - 1)) * (kBatchWords * 4);
+        u32 d[kWalkBatch];
+#pragma unroll
+        for (u32 k = 0; k < kWalkBatch; k++)
+          d[k] = group_lengths(*reinterpret_cast<const u32x4*>(lds_raw + slot + k * 1024 + lane * 16));
+        while (pos < bb + kBatchWords && g < groups) {  // same stepping as walker_advance
+          const u32 rel = pos - bb;
+          const u32 D = uniform(length_at(d, rel));
+          const u32 pj = rel + lane * D;
+          const bool inside = pj < kBatchWords;
+          const u32 dj = length_at(d, inside ? pj : rel);
+          const u64 ok = __ballot(inside && dj == D);
+          u32 m = (u32)__builtin_ctzll(~ok | (1ull << 63));
+          m = m == 63 && (ok >> 63) ? 64 : m;
+          m = m < groups - g ? m : groups - g;
+          if (lane < m) {
+            const u32 hv = ring_word(ring_off, bb + pj);
+            if ((hv & 0xC0C0C0C0u) || ((hv + 0x5F5F5F5Fu) & 0x80808080u)) bad = 1;
+            lds_st64(index_off + 8 * (g + lane), ((u64)hv << 32) | (bb + pj));
+          }
+          g = uniform(g + m);
+          pos = uniform(pos + m * D);
+        }
+        if (lane == 0) lds_st32(found_off, g);
+      }
+      barrier_lds();  // B_t
+      g = uniform(lds32(found_off));
+      ring_eval_groups(c, e, out, ring_off, g_before, g, wave);
+    }
+    if (wave == 0) {
+      // sentinel, flags and the VariableByte tail (read from global memory)
+      Walker w;
+      w.base = e.bp.base;
+      w.W = W;
+      w.rounded = e.bp.rounded;
+      w.groups = groups;
+      w.index_off = index_off;
+      w.pos = pos;
+      w.g = g;
+      w.bad = __any(bad) ? 1 : 0;
+      walker_finish(w, c, p);
+    }
+  }
+  __syncthreads();
+  eval_bp_tail(c, e, out, e.count);
 }
 
 template <u32 BASE, u32 IA, u32 IB>
@@ -947,6 +1161,9 @@ __device__ inline void decode_block(const WorkItem* __restrict__ items, const u3
     if ((it.debug_flags & 2) && s + 1 == hdr.n_steps) break;
     switch (uniform(st.kind)) {
       case S_MATERIALIZE: materialize<DOUBLE_KERNEL>(c, uniform(st.a[0]), uniform(st.a[1])); break;
+      case S_STREAM_ROOT:
+        if (!DOUBLE_KERNEL) stream_int_bp(c, uniform(st.a[0]), uniform(st.a[1]), uniform(st.a[2]));
+        break;
       case S_BITMAP_CLEAR: bitmap_clear(c, st); break;
       case S_BITMAP_SET: bitmap_set(c, st); break;
       case S_BITMAP_STARTS: bitmap_starts(c, st); break;

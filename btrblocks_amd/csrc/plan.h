@@ -83,6 +83,8 @@ enum : uint8_t {
   S_BITMAP_RANK = 6,    // a1 seq bitmap, a2 seq rank, a3 bit count, a4 expected popcount (or NONE),
                         // a5 status bit to raise on a mismatch
   S_NULLMAP = 7,        // a0 nullmap type, a1 seq bitmap (REGULAR/FLIPPED, else NONE), a3 row count
+  S_STREAM_ROOT = 8,    // a0 pipe id (B_BP base), a1 dst seq id, a2 seq id of the LDS ring: root step that
+                        // stages the payload through LDS, indexing and unpacking it batch by batch
 };
 // Element kinds of S_BITMAP_SET: the four member encodings of CRoaring's native serialization.
 enum : uint32_t { SET_ARRAY32 = 0, SET_ARRAY16 = 1, SET_BITSET = 2, SET_RUNS = 3 };
@@ -128,6 +130,7 @@ enum : uint32_t {
 };
 
 constexpr uint32_t kBlockThreads = 256;
+constexpr uint32_t kStreamRingBytes = 16 * 1024;  // LDS ring of the streamed root step (4 batches of 1024 words)
 constexpr uint32_t kLdsCapBytes = 64 * 1024;
 
 }  // namespace btrplan

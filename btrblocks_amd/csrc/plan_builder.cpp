@@ -474,7 +474,16 @@ void build_program(const ColumnSource& src, BuiltProgram& out) {
   else
     root = bld.dbl_node(src.payload_off, src.scheme, n, 0, desc);
   const uint32_t dst = bld.add_seq(LOC_DST, 0, n, src.column_type == COL_DOUBLE ? 8 : 4);
-  bld.add_step(S_MATERIALIZE, root, dst);
+  if (src.column_type == COL_INTEGER && bld.pipes[root].base == B_BP) {
+    // The root reads a full-length bit-packed stream: build its group index while decoding
+    // instead of in a separate pass over the payload.
+    auto& bs = bld.bp_steps;
+    bs.erase(std::remove_if(bs.begin(), bs.end(), [&](const Step& s) { return s.a[0] == root; }), bs.end());
+    const uint32_t ring = bld.add_seq(LOC_LDS, 0, kStreamRingBytes / 16, 16, true);
+    bld.add_step(S_STREAM_ROOT, root, dst, ring);
+  } else {
+    bld.add_step(S_MATERIALIZE, root, dst);
+  }
   if (src.want_nullmap) {
     if (src.nullmap_type == NM_REGULAR || src.nullmap_type == NM_FLIPPED) {
       const Builder::Bitmap bm = bld.add_bitmap(n);

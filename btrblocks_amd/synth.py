@@ -62,6 +62,10 @@ def double_decimal(n, seed=4, patch_fraction=0.01):
     return out
 
 
+def int_constant(n, seed=0):
+    return np.full(n, 123456 + seed, dtype=np.int32)
+
+
 def int_frequency(n, seed=5, top_fraction=0.99):
     """test/DatasetGenerator.cpp:290-325: one dominant value, rare random exceptions."""
     rng = np.random.default_rng(seed)
