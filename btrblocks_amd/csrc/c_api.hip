@@ -128,8 +128,9 @@ struct btr_gpu_plan {
   WorkItem* d_items = nullptr;
   uint8_t* d_programs = nullptr;
   uint32_t* d_status = nullptr;
-  uint32_t* d_order = nullptr;  // work item indices: integer columns first, then double columns
-  size_t n_int = 0, n_dbl = 0;
+  uint32_t* d_order = nullptr;  // work item indices grouped by the kernel that decodes them
+  size_t kind_begin[KERNEL_KINDS + 1] = {};
+  uint32_t kind_lds[KERNEL_KINDS] = {};  // dynamic LDS per launch
   uint8_t* d_scratch = nullptr;
   btr_plan_stats stats{};
   std::vector<uint32_t> h_status;
@@ -191,12 +192,15 @@ btr_status finish_plan(btr_gpu_ctx* ctx, std::vector<WorkItem>& items, std::vect
     if ((e = hipMemset(plan->d_status, 0, items.size() * 4)) != hipSuccess)
       return cleanup(hip_fail(e, "hipMemset(status)"));
     std::vector<uint32_t> order;
-    for (size_t i = 0; i < items.size(); i++)
-      if (!is_double[i]) order.push_back((uint32_t)i);
-    plan->n_int = order.size();
-    for (size_t i = 0; i < items.size(); i++)
-      if (is_double[i]) order.push_back((uint32_t)i);
-    plan->n_dbl = order.size() - plan->n_int;
+    for (uint32_t kind = 0; kind < KERNEL_KINDS; kind++) {
+      plan->kind_begin[kind] = order.size();
+      for (size_t i = 0; i < items.size(); i++)
+        if (progs[i].kernel == kind) {
+          order.push_back((uint32_t)i);
+          plan->kind_lds[kind] = std::max(plan->kind_lds[kind], progs[i].lds_bytes);
+        }
+    }
+    plan->kind_begin[KERNEL_KINDS] = order.size();
     if ((e = hipMalloc((void**)&plan->d_order, order.size() * 4)) != hipSuccess)
       return cleanup(hip_fail(e, "hipMalloc(order)"));
     if ((e = hipMemcpy(plan->d_order, order.data(), order.size() * 4, hipMemcpyHostToDevice)) != hipSuccess)
@@ -406,6 +410,7 @@ btr_status btr_gpu_ctx_create(int device, btr_gpu_ctx** out) {
   hipFuncAttributes attr;
   e = hipFuncGetAttributes(&attr, (const void*)btr_decode_int_kernel);
   if (e == hipSuccess) e = hipFuncGetAttributes(&attr, (const void*)btr_decode_dbl_kernel);
+  if (e == hipSuccess) e = hipFuncGetAttributes(&attr, (const void*)btr_stream_dict_lds_kernel);
   if (e != hipSuccess)
     return fail(BTR_ERR_DEVICE, std::string("decode kernel has no code object for this device (built for gfx950): ") +
                                     hipGetErrorString(e));
@@ -530,16 +535,16 @@ btr_status btr_gpu_decode(btr_gpu_ctx* ctx, btr_gpu_plan* plan, void* hip_stream
   if (plan->n_items == 0) return BTR_OK;
   DeviceGuard guard(plan->device);
   if (!guard.ok) return fail(BTR_ERR_DEVICE, "hipSetDevice failed");
-  if (plan->n_int) {
-    hipLaunchKernelGGL(btr_decode_int_kernel, dim3((unsigned)plan->n_int), dim3(kBlockThreads),
-                       plan->stats.max_lds_bytes, (hipStream_t)hip_stream, plan->d_items, plan->d_order,
+  using Kernel = void (*)(const WorkItem*, const uint32_t*, const uint8_t*, uint32_t*);
+  static const Kernel kernels[KERNEL_KINDS] = {btr_decode_int_kernel,      btr_decode_dbl_kernel,
+                                               btr_stream_none_kernel,     btr_stream_add_kernel,
+                                               btr_stream_dict_lds_kernel, btr_stream_dict_glb_kernel};
+  for (uint32_t kind = 0; kind < KERNEL_KINDS; kind++) {
+    const size_t n = plan->kind_begin[kind + 1] - plan->kind_begin[kind];
+    if (n == 0) continue;
+    hipLaunchKernelGGL(kernels[kind], dim3((unsigned)n), dim3(kBlockThreads), plan->kind_lds[kind],
+                       (hipStream_t)hip_stream, plan->d_items, plan->d_order + plan->kind_begin[kind],
                        plan->d_programs, plan->d_status);
-    HIP_TRY(hipGetLastError());
-  }
-  if (plan->n_dbl) {
-    hipLaunchKernelGGL(btr_decode_dbl_kernel, dim3((unsigned)plan->n_dbl), dim3(kBlockThreads),
-                       plan->stats.max_lds_bytes, (hipStream_t)hip_stream, plan->d_items,
-                       plan->d_order + plan->n_int, plan->d_programs, plan->d_status);
     HIP_TRY(hipGetLastError());
   }
   return BTR_OK;

@@ -113,6 +113,7 @@ struct Ctx {
   u32 steps_off, pipes_off, seqs_off;  // LDS byte offsets of the program tables
   u32 table_base;                      // LDS byte offset of table space
   u32 red_off;                         // 64 bytes of LDS for block-wide reductions
+  u32 debug;                           // WorkItem::debug_flags
 };
 
 __device__ inline const Step& step_at(const Ctx& c, u32 i) {
@@ -315,16 +316,29 @@ __device__ __forceinline__ IntEval resolve_int(const Ctx& c, u32 pipe_id) {
 
 // Dictionary gathers and FOR bias adds queued behind the base value
 // (templated/DynamicDictionary.hpp:125-158: dest[i] = dict[codes[i]]; integer/FOR.cpp:62-64).
-__device__ __forceinline__ u32 apply_posts(const Ctx& c, const IntEval& e, u32 v) {
+// The hot loops are instantiated per post-op signature so that no per-value branching remains;
+// a code outside the dictionary is clamped and remembered in `bad` (reported once per loop).
+enum : u32 { PS_NONE = 0, PS_ADD = 1, PS_DICT_LDS = 2, PS_DICT_GLB = 3, PS_GEN = 4 };
+
+__device__ __forceinline__ u32 post_signature(const IntEval& e) {
+  if (e.n_post == 0) return PS_NONE;
+  if (e.n_post == 1) {
+    if (e.post_type[0] == POST_ADD) return PS_ADD;
+    if (e.post_tab[0].count == 0) return PS_GEN;
+    return e.post_tab[0].loc == LOC_LDS ? PS_DICT_LDS : PS_DICT_GLB;
+  }
+  return PS_GEN;
+}
+
+__device__ __forceinline__ u32 apply_posts_generic(const IntEval& e, u32 v, u32& bad) {
 #pragma unroll
   for (int k = 0; k < MAX_POST; k++) {
     if (k < (int)e.n_post) {
       if (e.post_type[k] == POST_DICT) {
         const Tab& d = e.post_tab[k];
-        if (v >= d.count) {
-          raise(c, ST_DICT_CODE);
-          v = d.count ? d.count - 1 : 0;
-        }
+        const u32 n = d.count ? d.count : 1;
+        bad |= v >= d.count;
+        v = v < n ? v : n - 1;
         v = d.count ? tab_ld32(d, v) : 0;
       } else {
         v += e.post_bias[k];
@@ -332,6 +346,19 @@ __device__ __forceinline__ u32 apply_posts(const Ctx& c, const IntEval& e, u32 v
     }
   }
   return v;
+}
+
+template <u32 PS>
+__device__ __forceinline__ u32 apply_posts(const IntEval& e, u32 v, u32& bad) {
+  if (PS == PS_NONE) return v;
+  if (PS == PS_ADD) return v + e.post_bias[0];
+  if (PS == PS_DICT_LDS || PS == PS_DICT_GLB) {
+    const u32 n = e.post_tab[0].count;
+    bad |= v >= n;
+    v = v < n ? v : n - 1;
+    return PS == PS_DICT_LDS ? lds32(e.post_tab[0].lds + 4 * v) : ldg32(e.post_tab[0].g + 4ull * v);
+  }
+  return apply_posts_generic(e, v, bad);
 }
 
 template <u32 BASE, bool ALIGNED>
@@ -361,8 +388,8 @@ __device__ __forceinline__ u32 eval_int_base(const IntEval& e, u32 i) {
   return 0;
 }
 
-template <u32 BASE, bool ALIGNED>
-__device__ __forceinline__ u32 eval_int(const Ctx& c, const IntEval& e, u32 i) {
+template <u32 BASE, bool ALIGNED, u32 PS = PS_GEN>
+__device__ __forceinline__ u32 eval_int(const IntEval& e, u32 i, u32& bad) {
   u32 v;
   if (BASE != GEN) {
     v = eval_int_base<BASE, ALIGNED>(e, i);
@@ -376,7 +403,7 @@ __device__ __forceinline__ u32 eval_int(const Ctx& c, const IntEval& e, u32 i) {
       default: v = 0; break;
     }
   }
-  return apply_posts(c, e, v);
+  return apply_posts<PS>(e, v, bad);
 }
 
 // ---- resolved double pipe --------------------------------------------------------------------
@@ -442,8 +469,9 @@ __device__ __forceinline__ DblEval resolve_dbl(const Ctx& c, u32 pipe_id) {
 }
 
 // IA / IB: base kinds of the nested integer pipes when known at compile time, else GEN.
-template <u32 BASE, u32 IA, u32 IB>
-__device__ __forceinline__ u64 eval_dbl(const Ctx& c, const DblEval& e, u32 i) {
+// IPS: post-op signature of the nested integer pipes (PS_NONE when both are bare).
+template <u32 BASE, u32 IA, u32 IB, u32 IPS = PS_GEN>
+__device__ __forceinline__ u64 eval_dbl(const DblEval& e, u32 i, u32& bad) {
   if (BASE == B_SEQ) return tab_ld64(e.tab, i);
   if (BASE == B_ONE) return ((u64)e.k1 << 32) | e.k0;
   if (BASE == B_RLE) {
@@ -463,26 +491,23 @@ __device__ __forceinline__ u64 eval_dbl(const Ctx& c, const DblEval& e, u32 i) {
     return v;
   }
   if (BASE == B_DICTD) {
-    u32 code = eval_int<IA, true>(c, e.ia, i);
-    if (code >= e.tab.count) {
-      raise(c, ST_DICT_CODE);
-      code = e.tab.count ? e.tab.count - 1 : 0;
-    }
+    u32 code = eval_int<IA, true, IPS>(e.ia, i, bad);
+    const u32 n = e.tab.count ? e.tab.count : 1;
+    bad |= code >= e.tab.count;
+    code = code < n ? code : n - 1;
     return e.tab.count ? tab_ld64(e.tab, code) : 0;
   }
   if (BASE == B_PSEUDO) {
     // double/Pseudodecimal.cpp:424-436: exponent 23 takes the next patch, anything else is
     // double(int32 digits) * 10^-exponent - one exact conversion and one IEEE multiply.
-    const u32 ex = eval_int<IB, true>(c, e.ib, i);
+    const u32 ex = eval_int<IB, true, IPS>(e.ib, i, bad);
     bool member;
     const u32 xr = rank_lt(e.rk, i, &member);
     u32 di = i - xr;
     di = di < e.k0 ? di : (e.k0 ? e.k0 - 1 : 0);
-    const int digits = e.k0 ? (int)eval_int<IA, false>(c, e.ia, di) : 0;
+    const int digits = e.k0 ? (int)eval_int<IA, false, IPS>(e.ia, di, bad) : 0;
     u32 idx = ex & btrfmt::DEC_INDEX_MASK;
-    if (ex != btrfmt::DEC_EXCEPTION_CODE && idx > btrfmt::DEC_MAX_EXPONENT) {
-      raise(c, ST_EXPONENT);
-    }
+    bad |= (ex != btrfmt::DEC_EXCEPTION_CODE && idx > btrfmt::DEC_MAX_EXPONENT) ? 2u : 0u;
     idx = idx > btrfmt::DEC_MAX_EXPONENT ? btrfmt::DEC_MAX_EXPONENT : idx;
     u64 r = (u64)__double_as_longlong((double)digits * kFractions[idx]);
     if (ex == btrfmt::DEC_EXCEPTION_CODE) {
@@ -631,7 +656,11 @@ __device__ __forceinline__ void walker_advance(Walker& w, u32 until) {
 
 // After the last group: flags, the end-of-packing sentinel and the VariableByte tail (fewer
 // than 32 values: 7 bits per byte, low group first, a set top bit ends a value).
-__device__ __forceinline__ void walker_finish(Walker& w, const Ctx& c, const Pipe& p) {
+struct WalkEnd {
+  const u8* base;
+  u32 W, rounded, groups, index_off, pos, g, bad;
+};
+__device__ __forceinline__ void walker_finish(const WalkEnd& w, const Ctx& c, const Pipe& p) {
   const u32 lane = threadIdx.x & 63;
   u32 bad = w.bad | (w.g < w.groups);  // the stream ended before all groups were found
   u32 pos = w.pos;
@@ -672,21 +701,27 @@ __device__ void bp_index_wave(const Ctx& c, const Pipe& p) {
   Walker w;
   walker_init(w, c, p);
   walker_advance(w, w.groups);
-  walker_finish(w, c, p);
+  walker_finish(WalkEnd{w.base, w.W, w.rounded, w.groups, w.index_off, w.pos, w.g, w.bad}, c, p);
 }
 
 // ---- step: materialize a pipe into a sequence ----------------------------------------------------
 constexpr u32 kUnroll = 4;
 
-template <u32 BASE>
+__device__ __forceinline__ void report(const Ctx& c, u32 bad) {
+  if (bad & 1) raise(c, ST_DICT_CODE);
+  if (bad & 2) raise(c, ST_EXPONENT);
+}
+
+template <u32 BASE, u32 PS>
 __device__ __forceinline__ void mat_int(const Ctx& c, const IntEval& e, const Tab& out, u32 count) {
   const u32 tid = threadIdx.x;
+  u32 bad = 0;
   for (u32 base = 0; base < count; base += kBlockThreads * kUnroll) {
     u32 v[kUnroll];
 #pragma unroll
     for (u32 u = 0; u < kUnroll; u++) {
       const u32 i = base + u * kBlockThreads + tid;
-      v[u] = eval_int<BASE, true>(c, e, i < count ? i : count - 1);
+      v[u] = eval_int<BASE, true, PS>(e, i < count ? i : count - 1, bad);
     }
 #pragma unroll
     for (u32 u = 0; u < kUnroll; u++) {
@@ -694,44 +729,56 @@ __device__ __forceinline__ void mat_int(const Ctx& c, const IntEval& e, const Ta
       if (i < count) tab_st32(out, i, v[u]);
     }
   }
+  report(c, bad);
 }
 
-// Root loop for a bit-packed base: every wave takes whole 128-value groups, lane l produces
-// values l and l+64 of the group (miniblocks l/32 and 2+l/32), so the header and the miniblock
-// offsets are wave-uniform and a group's 128 values are stored as two contiguous 256-byte rows.
+// Widths and first words of the four miniblocks of a group, per lane: lanes 0-31 work on
+// miniblocks 0 and 2, lanes 32-63 on miniblocks 1 and 3 (values lane and lane + 64 of the group).
+struct LaneGroup {
+  u32 w_lo, b_lo, w_hi, b_hi;
+};
+__device__ __forceinline__ LaneGroup lane_group(u64 index_entry, u32 upper_mask) {
+  const u32 off = uniform((u32)index_entry), hdr = uniform((u32)(index_entry >> 32));
+  u32 b0 = hdr >> 24, b1 = (hdr >> 16) & 0xFF, b2 = (hdr >> 8) & 0xFF, b3 = hdr & 0xFF;
+  b0 = b0 > 32 ? 32 : b0;
+  b1 = b1 > 32 ? 32 : b1;
+  b2 = b2 > 32 ? 32 : b2;
+  b3 = b3 > 32 ? 32 : b3;
+  const u32 first = off + 1;
+  LaneGroup g;  // branch-free selects: upper_mask is all ones in lanes 32-63
+  g.w_lo = first + (b0 & upper_mask);
+  g.b_lo = (b0 & ~upper_mask) | (b1 & upper_mask);
+  g.w_hi = first + b0 + b1 + (b2 & upper_mask);
+  g.b_hi = (b2 & ~upper_mask) | (b3 & upper_mask);
+  return g;
+}
+
+// Groups [g_lo, g_hi) of a bit-packed root read from global memory: every wave takes whole
+// 128-value groups.
 constexpr u32 kGroupsPerIter = 4;
 
-// Groups [g_lo, g_hi) of a bit-packed root: every wave takes whole 128-value groups.
+template <u32 PS>
 __device__ __forceinline__ void eval_bp_groups(const Ctx& c, const IntEval& e, const Tab& out, u32 g_lo,
                                                u32 g_hi) {
   const u32 lane = threadIdx.x & 63, wave = uniform(threadIdx.x >> 6);
   const BpView& bp = e.bp;
   const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(bp.base, bp.bytes);
   const u32 k = lane & 31;
-  const bool upper = lane >= 32;
+  const u32 upper_mask = lane >= 32 ? ~0u : 0u;
+  u32 bad = 0;
   for (u32 g0 = g_lo + wave * kGroupsPerIter; g0 < g_hi; g0 += (kBlockThreads / 64) * kGroupsPerIter) {
     u32 v[kGroupsPerIter][2];
 #pragma unroll
     for (u32 j = 0; j < kGroupsPerIter; j++) {
       const u32 g = g0 + j < g_hi ? g0 + j : g_hi - 1;
-      const u64 ih = lds64(bp.index_off + 8 * g);
-      const u32 off = uniform((u32)ih), hdr = uniform((u32)(ih >> 32));
-      u32 b0 = hdr >> 24, b1 = (hdr >> 16) & 0xFF, b2 = (hdr >> 8) & 0xFF, b3 = hdr & 0xFF;
-      b0 = b0 > 32 ? 32 : b0;
-      b1 = b1 > 32 ? 32 : b1;
-      b2 = b2 > 32 ? 32 : b2;
-      b3 = b3 > 32 ? 32 : b3;
-      const u32 first = off + 1;
-      // miniblocks 0/1 (value lane) and 2/3 (value lane + 64)
-      const u32 w_lo = upper ? first + b0 : first;
-      const u32 w_hi = upper ? first + b0 + b1 + b2 : first + b0 + b1;
-      v[j][0] = bp_extract(rsrc, w_lo, upper ? b1 : b0, k);
-      v[j][1] = bp_extract(rsrc, w_hi, upper ? b3 : b2, k);
+      const LaneGroup lg = lane_group(lds64(bp.index_off + 8 * g), upper_mask);
+      v[j][0] = bp_extract(rsrc, lg.w_lo, lg.b_lo, k);
+      v[j][1] = bp_extract(rsrc, lg.w_hi, lg.b_hi, k);
     }
 #pragma unroll
     for (u32 j = 0; j < kGroupsPerIter; j++) {
-      v[j][0] = apply_posts(c, e, v[j][0]);
-      v[j][1] = apply_posts(c, e, v[j][1]);
+      v[j][0] = apply_posts<PS>(e, v[j][0], bad);
+      v[j][1] = apply_posts<PS>(e, v[j][1], bad);
     }
 #pragma unroll
     for (u32 j = 0; j < kGroupsPerIter; j++) {
@@ -742,17 +789,22 @@ __device__ __forceinline__ void eval_bp_groups(const Ctx& c, const IntEval& e, c
       }
     }
   }
+  report(c, bad);
 }
 
+template <u32 PS>
 __device__ __forceinline__ void eval_bp_tail(const Ctx& c, const IntEval& e, const Tab& out, u32 count) {
   const BpView& bp = e.bp;
+  u32 bad = 0;
   for (u32 i = bp.rounded + threadIdx.x; i < count; i += kBlockThreads)
-    tab_st32(out, i, apply_posts(c, e, lds32(bp.tail_off + 4 * ((i - bp.rounded) & 31))));
+    tab_st32(out, i, apply_posts<PS>(e, lds32(bp.tail_off + 4 * ((i - bp.rounded) & 31)), bad));
+  report(c, bad);
 }
 
+template <u32 PS>
 __device__ __forceinline__ void mat_int_bp(const Ctx& c, const IntEval& e, const Tab& out, u32 count) {
-  eval_bp_groups(c, e, out, 0, (e.bp.rounded + btrfmt::FBP_GROUP - 1) / btrfmt::FBP_GROUP);
-  eval_bp_tail(c, e, out, count);
+  eval_bp_groups<PS>(c, e, out, 0, (e.bp.rounded + btrfmt::FBP_GROUP - 1) / btrfmt::FBP_GROUP);
+  eval_bp_tail<PS>(c, e, out, count);
 }
 
 // ---- root step over a bit-packed stream, payload staged through an LDS ring ------------------------
@@ -765,10 +817,10 @@ __device__ __forceinline__ void mat_int_bp(const Ctx& c, const IntEval& e, const
 //   waves 0-2        unpack the groups found in that batch from the ring and store the rows.
 // Two workgroup barriers per batch: A "batch t+1 has landed" (a group that starts in batch t may
 // run into batch t+1), B "the groups of batch t are indexed".
-constexpr u32 kRingBatches = 4;                 // power of two
-constexpr u32 kRingAhead = 3;                   // batches issued ahead of the one being walked
+constexpr u32 kRingBatches = 4;  // power of two
+constexpr u32 kRingAhead = 3;    // batches issued ahead of the one being walked
 constexpr u32 kRingWords = kRingBatches * kBatchWords;
-constexpr u32 kRingBytes = kRingWords * 4;
+static_assert(kRingWords * 4 == kStreamRingBytes, "ring size is shared with the plan compiler");
 
 __device__ __forceinline__ void barrier_lds() {  // LDS writes of this wave visible, then barrier
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -776,7 +828,9 @@ __device__ __forceinline__ void barrier_lds() {  // LDS writes of this wave visi
   asm volatile("" ::: "memory");
 }
 
-__device__ __forceinline__ u32 ring_word(u32 ring_off, u32 w) { return lds32(ring_off + ((w & (kRingWords - 1)) << 2)); }
+__device__ __forceinline__ u32 ring_word(u32 ring_off, u32 w) {
+  return lds32(ring_off + ((w & (kRingWords - 1)) << 2));
+}
 
 __device__ __forceinline__ u32 ring_extract(u32 ring_off, u32 base_word, u32 b, u32 k) {
   const u32 bit = k * b;
@@ -786,43 +840,39 @@ __device__ __forceinline__ u32 ring_extract(u32 ring_off, u32 base_word, u32 b, 
   return b >= 32 ? v : (v & ((1u << b) - 1u));
 }
 
-constexpr u32 kRingGroupsPerIter = 2;
+constexpr u32 kRingGroupsPerIter = 4;
 constexpr u32 kRingWorkers = 3;
 
 // Groups [g_lo, g_hi) unpacked from the ring by waves 0..2; lane l produces values l and l+64.
+template <u32 PS>
 __device__ __forceinline__ void ring_eval_groups(const Ctx& c, const IntEval& e, const Tab& out, u32 ring_off,
-                                                 u32 g_lo, u32 g_hi, u32 wave) {
+                                                 u32 g_lo, u32 g_hi, u32 wave, u32& bad) {
   const u32 lane = threadIdx.x & 63;
   const BpView& bp = e.bp;
   const u32 k = lane & 31;
-  const bool upper = lane >= 32;
+  const u32 upper_mask = lane >= 32 ? ~0u : 0u;
   for (u32 g0 = g_lo + wave * kRingGroupsPerIter; g0 < g_hi; g0 += kRingWorkers * kRingGroupsPerIter) {
     u32 v[kRingGroupsPerIter][2];
 #pragma unroll
     for (u32 j = 0; j < kRingGroupsPerIter; j++) {
       const u32 g = g0 + j < g_hi ? g0 + j : g_hi - 1;
-      const u64 ih = lds64(bp.index_off + 8 * g);
-      const u32 off = uniform((u32)ih), hdr = uniform((u32)(ih >> 32));
-      u32 b0 = hdr >> 24, b1 = (hdr >> 16) & 0xFF, b2 = (hdr >> 8) & 0xFF, b3 = hdr & 0xFF;
-      b0 = b0 > 32 ? 32 : b0;
-      b1 = b1 > 32 ? 32 : b1;
-      b2 = b2 > 32 ? 32 : b2;
-      b3 = b3 > 32 ? 32 : b3;
-      const u32 first = off + 1;
-      const u32 w_lo = upper ? first + b0 : first;
-      const u32 w_hi = upper ? first + b0 + b1 + b2 : first + b0 + b1;
-      v[j][0] = ring_extract(ring_off, w_lo, upper ? b1 : b0, k);
-      v[j][1] = ring_extract(ring_off, w_hi, upper ? b3 : b2, k);
+      const LaneGroup lg = lane_group(lds64(bp.index_off + 8 * g), upper_mask);
+      v[j][0] = ring_extract(ring_off, lg.w_lo, lg.b_lo, k);
+      v[j][1] = ring_extract(ring_off, lg.w_hi, lg.b_hi, k);
     }
 #pragma unroll
     for (u32 j = 0; j < kRingGroupsPerIter; j++) {
-      v[j][0] = apply_posts(c, e, v[j][0]);
-      v[j][1] = apply_posts(c, e, v[j][1]);
+      v[j][0] = apply_posts<PS>(e, v[j][0], bad);
+      v[j][1] = apply_posts<PS>(e, v[j][1], bad);
     }
 #pragma unroll
     for (u32 j = 0; j < kRingGroupsPerIter; j++) {
       const u32 i = (g0 + j) * btrfmt::FBP_GROUP + lane;
       if (g0 + j < g_hi) {
+        if (c.debug & 16) {  // timing diagnostics: keep the values live without storing them
+          asm volatile("" ::"v"(v[j][0]), "v"(v[j][1]));
+          continue;
+        }
         if (i < bp.rounded) tab_st32(out, i, v[j][0]);
         if (i + 64 < bp.rounded) tab_st32(out, i + 64, v[j][1]);
       }
@@ -830,11 +880,9 @@ __device__ __forceinline__ void ring_eval_groups(const Ctx& c, const IntEval& e,
   }
 }
 
-__device__ void stream_int_bp(const Ctx& c, u32 pipe_id, u32 seq_id, u32 ring_seq) {
-  const Pipe& p = pipe_at(c, pipe_id);
-  const IntEval e = resolve_int(c, pipe_id);
-  const Tab out = resolve_tab(c, seq_id);
-  const u32 ring_off = seq_lds(c, ring_seq);
+template <u32 PS>
+__device__ __forceinline__ void stream_int_bp(const Ctx& c, const Pipe& p, const IntEval& e, const Tab& out,
+                                              u32 ring_off) {
   const u32 lane = threadIdx.x & 63, wave = uniform(threadIdx.x >> 6);
   const u32 W = uniform(p.a[1]), groups = uniform(p.a[5]);
   const u32 index_off = e.bp.index_off;
@@ -866,12 +914,12 @@ __device__ void stream_int_bp(const Ctx& c, u32 pipe_id, u32 seq_id, u32 ring_se
     }
   } else {
     // ---- walker (wave 0) and unpackers (waves 0..2)
-    u32 pos = 1, g = 0, bad = 0;
+    u32 pos = 1, g = 0, bad_hdr = 0, bad = 0;
     for (u32 t = 0; t < batches; t++) {
       const u32 g_before = g;
       __builtin_amdgcn_s_barrier();  // A_t
       asm volatile("" ::: "memory");
-      if (wave == 0) {
+      if (wave == 0 && !(c.debug & 4)) {
         const u32 bb = t * kBatchWords;
         const u32 slot = ring_off + (t & (kRingBatches - 1)) * (kBatchWords * 4);
         u32 d[kWalkBatch];
@@ -890,7 +938,7 @@ __device__ void stream_int_bp(const Ctx& c, u32 pipe_id, u32 seq_id, u32 ring_se
           m = m < groups - g ? m : groups - g;
           if (lane < m) {
             const u32 hv = ring_word(ring_off, bb + pj);
-            if ((hv & 0xC0C0C0C0u) || ((hv + 0x5F5F5F5Fu) & 0x80808080u)) bad = 1;
+            if ((hv & 0xC0C0C0C0u) || ((hv + 0x5F5F5F5Fu) & 0x80808080u)) bad_hdr = 1;
             lds_st64(index_off + 8 * (g + lane), ((u64)hv << 32) | (bb + pj));
           }
           g = uniform(g + m);
@@ -900,41 +948,46 @@ __device__ void stream_int_bp(const Ctx& c, u32 pipe_id, u32 seq_id, u32 ring_se
       }
       barrier_lds();  // B_t
       g = uniform(lds32(found_off));
-      ring_eval_groups(c, e, out, ring_off, g_before, g, wave);
+      if (c.debug & 4) g = (t + 1) * 21 < groups ? (t + 1) * 21 : groups;  // timing diagnostics
+      if (!(c.debug & 8)) ring_eval_groups<PS>(c, e, out, ring_off, g_before, g, wave, bad);
     }
+    report(c, bad);
     if (wave == 0) {
       // sentinel, flags and the VariableByte tail (read from global memory)
-      Walker w;
-      w.base = e.bp.base;
-      w.W = W;
-      w.rounded = e.bp.rounded;
-      w.groups = groups;
-      w.index_off = index_off;
-      w.pos = pos;
-      w.g = g;
-      w.bad = __any(bad) ? 1 : 0;
-      walker_finish(w, c, p);
+      walker_finish(WalkEnd{e.bp.base, W, e.bp.rounded, groups, index_off, pos, g, __any(bad_hdr) ? 1u : 0u}, c, p);
     }
   }
   __syncthreads();
-  eval_bp_tail(c, e, out, e.count);
+  eval_bp_tail<PS>(c, e, out, e.count);
 }
 
-template <u32 BASE, u32 IA, u32 IB>
+template <u32 BASE, u32 IA, u32 IB, u32 IPS>
 __device__ __forceinline__ void mat_dbl(const Ctx& c, const DblEval& e, const Tab& out, u32 count) {
   const u32 tid = threadIdx.x;
+  u32 bad = 0;
   for (u32 base = 0; base < count; base += kBlockThreads * kUnroll) {
     u64 v[kUnroll];
 #pragma unroll
     for (u32 u = 0; u < kUnroll; u++) {
       const u32 i = base + u * kBlockThreads + tid;
-      v[u] = eval_dbl<BASE, IA, IB>(c, e, i < count ? i : count - 1);
+      v[u] = eval_dbl<BASE, IA, IB, IPS>(e, i < count ? i : count - 1, bad);
     }
 #pragma unroll
     for (u32 u = 0; u < kUnroll; u++) {
       const u32 i = base + u * kBlockThreads + tid;
       if (i < count) tab_st64(out, i, v[u]);
     }
+  }
+  report(c, bad);
+}
+
+template <u32 BASE>
+__device__ __forceinline__ void mat_int_ps(const Ctx& c, const IntEval& e, const Tab& out, u32 count) {
+  switch (post_signature(e)) {
+    case PS_NONE: mat_int<BASE, PS_NONE>(c, e, out, count); break;
+    case PS_ADD: mat_int<BASE, PS_ADD>(c, e, out, count); break;
+    case PS_DICT_LDS: mat_int<BASE, PS_DICT_LDS>(c, e, out, count); break;
+    default: mat_int<BASE, PS_GEN>(c, e, out, count); break;
   }
 }
 
@@ -947,33 +1000,41 @@ __device__ __forceinline__ void materialize(const Ctx& c, u32 pipe_id, u32 seq_i
   if (!is_double) {
     const IntEval e = resolve_int(c, pipe_id);
     switch (e.base) {
-      case B_SEQ: mat_int<B_SEQ>(c, e, out, count); break;
-      case B_ONE: mat_int<B_ONE>(c, e, out, count); break;
-      case B_BP: mat_int_bp(c, e, out, count); break;
-      case B_RLE: mat_int<B_RLE>(c, e, out, count); break;
-      case B_FREQ: mat_int<B_FREQ>(c, e, out, count); break;
+      case B_SEQ: mat_int_ps<B_SEQ>(c, e, out, count); break;
+      case B_ONE: mat_int<B_ONE, PS_GEN>(c, e, out, count); break;
+      case B_BP:
+        switch (post_signature(e)) {
+          case PS_NONE: mat_int_bp<PS_NONE>(c, e, out, count); break;
+          case PS_ADD: mat_int_bp<PS_ADD>(c, e, out, count); break;
+          case PS_DICT_LDS: mat_int_bp<PS_DICT_LDS>(c, e, out, count); break;
+          default: mat_int_bp<PS_GEN>(c, e, out, count); break;
+        }
+        break;
+      case B_RLE: mat_int_ps<B_RLE>(c, e, out, count); break;
+      case B_FREQ: mat_int<B_FREQ, PS_GEN>(c, e, out, count); break;
       default: break;
     }
   } else if (DOUBLE_KERNEL) {
     const DblEval e = resolve_dbl(c, pipe_id);
+    const bool bare = e.ia.n_post == 0 && e.ib.n_post == 0;
     switch (e.base) {
-      case B_SEQ: mat_dbl<B_SEQ, GEN, GEN>(c, e, out, count); break;
-      case B_ONE: mat_dbl<B_ONE, GEN, GEN>(c, e, out, count); break;
-      case B_RLE: mat_dbl<B_RLE, GEN, GEN>(c, e, out, count); break;
-      case B_FREQ: mat_dbl<B_FREQ, GEN, GEN>(c, e, out, count); break;
+      case B_SEQ: mat_dbl<B_SEQ, GEN, GEN, PS_GEN>(c, e, out, count); break;
+      case B_ONE: mat_dbl<B_ONE, GEN, GEN, PS_GEN>(c, e, out, count); break;
+      case B_RLE: mat_dbl<B_RLE, GEN, GEN, PS_GEN>(c, e, out, count); break;
+      case B_FREQ: mat_dbl<B_FREQ, GEN, GEN, PS_GEN>(c, e, out, count); break;
       case B_DICTD:
-        if (e.ia.base == B_BP)
-          mat_dbl<B_DICTD, B_BP, GEN>(c, e, out, count);
+        if (e.ia.base == B_BP && bare)
+          mat_dbl<B_DICTD, B_BP, GEN, PS_NONE>(c, e, out, count);
         else
-          mat_dbl<B_DICTD, GEN, GEN>(c, e, out, count);
+          mat_dbl<B_DICTD, GEN, GEN, PS_GEN>(c, e, out, count);
         break;
       case B_PSEUDO:
-        if (e.ib.base == B_BP && (e.ia.base == B_BP || e.k0 == 0))
-          mat_dbl<B_PSEUDO, B_BP, B_BP>(c, e, out, count);
+        if (e.ib.base == B_BP && (e.ia.base == B_BP || e.k0 == 0) && bare)
+          mat_dbl<B_PSEUDO, B_BP, B_BP, PS_NONE>(c, e, out, count);
         else
-          mat_dbl<B_PSEUDO, GEN, GEN>(c, e, out, count);
+          mat_dbl<B_PSEUDO, GEN, GEN, PS_GEN>(c, e, out, count);
         break;
-      case B_DBP: mat_dbl<B_DBP, B_BP, GEN>(c, e, out, count); break;
+      case B_DBP: mat_dbl<B_DBP, B_BP, GEN, PS_NONE>(c, e, out, count); break;
       default: break;
     }
   }
@@ -1077,13 +1138,16 @@ __device__ void bitmap_eq(const Ctx& c, const Step& s) {
   const IntEval e = resolve_int(c, uniform(s.a[0]));
   const u32 bits_off = seq_lds(c, uniform(s.a[1]));
   const u32 nbits = uniform(s.a[3]), value = uniform(s.a[4]);
+  u32 bad = 0;
   for (u32 base = 0; base < nbits; base += kBlockThreads) {
     const u32 i = base + threadIdx.x;
     const u32 ii = i < nbits ? i : nbits - 1;
-    const u32 v = e.base == B_BP ? eval_int<B_BP, true>(c, e, ii) : eval_int<GEN, true>(c, e, ii);
+    const u32 v = (e.base == B_BP && e.n_post == 0) ? eval_int<B_BP, true, PS_NONE>(e, ii, bad)
+                                                     : eval_int<GEN, true, PS_GEN>(e, ii, bad);
     const u64 m = __ballot(i < nbits && v == value);
     if ((threadIdx.x & 63) == 0 && (i >> 6) <= (nbits >> 6)) lds_st64(bits_off + 8 * (i >> 6), m);
   }
+  report(c, bad);
 }
 
 __device__ void bitmap_rank(const Ctx& c, const Step& s) {
@@ -1121,11 +1185,9 @@ __device__ void write_nullmap(const Ctx& c, const Step& s) {
   }
 }
 
-template <bool DOUBLE_KERNEL>
-__device__ inline void decode_block(const WorkItem* __restrict__ items, const u32* __restrict__ order,
-                                    const u8* __restrict__ programs, u32* __restrict__ status) {
-  const u32 item = order[blockIdx.x];
-  const WorkItem it = items[item];
+// Copies the work item's program into LDS and sets up the workgroup context.
+__device__ __forceinline__ ProgramHeader load_program(const WorkItem& it, u32 item, const u8* __restrict__ programs,
+                                                      u32* __restrict__ status, Ctx& c) {
   const u32 tid = threadIdx.x;
   {
     const u32* prog = reinterpret_cast<const u32*>(programs + it.prog_off);
@@ -1138,7 +1200,6 @@ __device__ inline void decode_block(const WorkItem* __restrict__ items, const u3
   hdr.n_bp_steps = uniform(hdr.n_bp_steps);
   hdr.n_pipes = uniform(hdr.n_pipes);
   hdr.table_base = uniform(hdr.table_base);
-  Ctx c;
   c.src = reinterpret_cast<const u8*>(it.src);
   c.dst = reinterpret_cast<u8*>(it.dst);
   c.nullmap = reinterpret_cast<u8*>(it.nullmap_dst);
@@ -1149,6 +1210,40 @@ __device__ inline void decode_block(const WorkItem* __restrict__ items, const u3
   c.seqs_off = c.pipes_off + hdr.n_pipes * sizeof(Pipe);
   c.table_base = hdr.table_base;
   c.red_off = hdr.table_base - 64;
+  c.debug = it.debug_flags;
+  return hdr;
+}
+
+// Lean kernel body for chunks whose program is [optional dictionary copy into LDS] + streamed
+// bit-packed root: DICT(BP), FOR(BP) and plain BP integer columns.
+template <u32 PS>
+__device__ __forceinline__ void stream_block(const WorkItem* __restrict__ items, const u32* __restrict__ order,
+                                             const u8* __restrict__ programs, u32* __restrict__ status) {
+  const u32 item = order[blockIdx.x];
+  const WorkItem it = items[item];
+  Ctx c;
+  const ProgramHeader hdr = load_program(it, item, programs, status, c);
+  for (u32 s = 0; s + 1 < hdr.n_steps; s++) {  // dictionary copies: a bare source sequence -> LDS
+    const Step& st = step_at(c, s);
+    const Tab from = resolve_tab(c, uniform(pipe_at(c, uniform(st.a[0])).a[0]));
+    const Tab to = resolve_tab(c, uniform(st.a[1]));
+    for (u32 i = threadIdx.x; i < to.count; i += kBlockThreads) lds_st32(to.lds + 4 * i, ldg32(from.g + 4ull * i));
+  }
+  __syncthreads();
+  const Step& root = step_at(c, hdr.n_steps - 1);
+  const u32 pipe_id = uniform(root.a[0]);
+  const IntEval e = resolve_int(c, pipe_id);
+  stream_int_bp<PS>(c, pipe_at(c, pipe_id), e, resolve_tab(c, uniform(root.a[1])), seq_lds(c, uniform(root.a[2])));
+}
+
+template <bool DOUBLE_KERNEL>
+__device__ inline void decode_block(const WorkItem* __restrict__ items, const u32* __restrict__ order,
+                                    const u8* __restrict__ programs, u32* __restrict__ status) {
+  const u32 item = order[blockIdx.x];
+  const WorkItem it = items[item];
+  const u32 tid = threadIdx.x;
+  Ctx c;
+  const ProgramHeader hdr = load_program(it, item, programs, status, c);
 
   // bit-unpack indexes: one stream per wave, streams in parallel
   if (!(it.debug_flags & 1))
@@ -1161,9 +1256,6 @@ __device__ inline void decode_block(const WorkItem* __restrict__ items, const u3
     if ((it.debug_flags & 2) && s + 1 == hdr.n_steps) break;
     switch (uniform(st.kind)) {
       case S_MATERIALIZE: materialize<DOUBLE_KERNEL>(c, uniform(st.a[0]), uniform(st.a[1])); break;
-      case S_STREAM_ROOT:
-        if (!DOUBLE_KERNEL) stream_int_bp(c, uniform(st.a[0]), uniform(st.a[1]), uniform(st.a[2]));
-        break;
       case S_BITMAP_CLEAR: bitmap_clear(c, st); break;
       case S_BITMAP_SET: bitmap_set(c, st); break;
       case S_BITMAP_STARTS: bitmap_starts(c, st); break;
@@ -1190,4 +1282,26 @@ extern "C" __global__ void __launch_bounds__(kBlockThreads)
 btr_decode_dbl_kernel(const WorkItem* __restrict__ items, const u32* __restrict__ order,
                       const u8* __restrict__ programs, u32* __restrict__ status) {
   decode_block<true>(items, order, programs, status);
+}
+
+// Streamed bit-packed integer roots, one kernel per post-op signature (plan.h: KERNEL_STREAM_*).
+extern "C" __global__ void __launch_bounds__(kBlockThreads)
+btr_stream_none_kernel(const WorkItem* __restrict__ items, const u32* __restrict__ order,
+                       const u8* __restrict__ programs, u32* __restrict__ status) {
+  stream_block<PS_NONE>(items, order, programs, status);
+}
+extern "C" __global__ void __launch_bounds__(kBlockThreads)
+btr_stream_add_kernel(const WorkItem* __restrict__ items, const u32* __restrict__ order,
+                      const u8* __restrict__ programs, u32* __restrict__ status) {
+  stream_block<PS_ADD>(items, order, programs, status);
+}
+extern "C" __global__ void __launch_bounds__(kBlockThreads)
+btr_stream_dict_lds_kernel(const WorkItem* __restrict__ items, const u32* __restrict__ order,
+                           const u8* __restrict__ programs, u32* __restrict__ status) {
+  stream_block<PS_DICT_LDS>(items, order, programs, status);
+}
+extern "C" __global__ void __launch_bounds__(kBlockThreads)
+btr_stream_dict_glb_kernel(const WorkItem* __restrict__ items, const u32* __restrict__ order,
+                           const u8* __restrict__ programs, u32* __restrict__ status) {
+  stream_block<PS_DICT_GLB>(items, order, programs, status);
 }

@@ -129,6 +129,18 @@ enum : uint32_t {
   ST_EXPONENT = 1u << 6,    // Pseudodecimal exponent index above 22
 };
 
+// Which kernel decodes a work item. The generic kernels interpret any program; the stream kernels
+// take programs of the form [dictionary copy into LDS]* + S_STREAM_ROOT.
+enum : uint32_t {
+  KERNEL_GENERIC_INT = 0,
+  KERNEL_GENERIC_DBL = 1,
+  KERNEL_STREAM_NONE = 2,      // BP
+  KERNEL_STREAM_ADD = 3,       // FOR(BP)
+  KERNEL_STREAM_DICT_LDS = 4,  // DICT(BP), dictionary staged in LDS
+  KERNEL_STREAM_DICT_GLB = 5,  // DICT(BP), dictionary read from the compressed bytes
+  KERNEL_KINDS = 6,
+};
+
 constexpr uint32_t kBlockThreads = 256;
 constexpr uint32_t kStreamRingBytes = 16 * 1024;  // LDS ring of the streamed root step (4 batches of 1024 words)
 constexpr uint32_t kLdsCapBytes = 64 * 1024;

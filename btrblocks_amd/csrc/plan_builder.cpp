@@ -474,15 +474,30 @@ void build_program(const ColumnSource& src, BuiltProgram& out) {
   else
     root = bld.dbl_node(src.payload_off, src.scheme, n, 0, desc);
   const uint32_t dst = bld.add_seq(LOC_DST, 0, n, src.column_type == COL_DOUBLE ? 8 : 4);
-  if (src.column_type == COL_INTEGER && bld.pipes[root].base == B_BP) {
-    // The root reads a full-length bit-packed stream: build its group index while decoding
-    // instead of in a separate pass over the payload.
-    auto& bs = bld.bp_steps;
-    bs.erase(std::remove_if(bs.begin(), bs.end(), [&](const Step& s) { return s.a[0] == root; }), bs.end());
-    const uint32_t ring = bld.add_seq(LOC_LDS, 0, kStreamRingBytes / 16, 16, true);
-    bld.add_step(S_STREAM_ROOT, root, dst, ring);
-  } else {
-    bld.add_step(S_MATERIALIZE, root, dst);
+  uint32_t kernel = src.column_type == COL_DOUBLE ? KERNEL_GENERIC_DBL : KERNEL_GENERIC_INT;
+  // A root that reads one full-length bit-packed stream behind at most one post-op (BP, FOR(BP),
+  // DICT(BP)) goes to the stream kernels: its only preparation may be dictionary copies into
+  // LDS, and its group index is built while decoding instead of in a separate pass.
+  {
+    const Pipe& rp = bld.pipes[root];
+    bool eligible = src.column_type == COL_INTEGER && rp.base == B_BP && rp.n_post <= 1 &&
+                    !src.want_nullmap && bld.bp_steps.size() == 1 && n > 0;
+    for (const Step& st : bld.steps)
+      eligible = eligible && st.kind == S_MATERIALIZE && bld.pipes[st.a[0]].base == B_SEQ &&
+                 bld.pipes[st.a[0]].n_post == 0 && bld.seqs[st.a[1]].esize == 4;
+    if (eligible) {
+      bld.bp_steps.clear();
+      const uint32_t ring = bld.add_seq(LOC_LDS, 0, kStreamRingBytes / 16, 16, true);
+      bld.add_step(S_STREAM_ROOT, root, dst, ring);
+      if (rp.n_post == 0)
+        kernel = KERNEL_STREAM_NONE;
+      else if (rp.post[0].type == POST_ADD)
+        kernel = KERNEL_STREAM_ADD;
+      else
+        kernel = KERNEL_STREAM_DICT_LDS;  // corrected below once table placement is known
+    } else {
+      bld.add_step(S_MATERIALIZE, root, dst);
+    }
   }
   if (src.want_nullmap) {
     if (src.nullmap_type == NM_REGULAR || src.nullmap_type == NM_FLIPPED) {
@@ -525,10 +540,28 @@ void build_program(const ColumnSource& src, BuiltProgram& out) {
                                         std::to_string(table_base + lds) + " bytes)");
   if (scratch > 0xFFFFFFFFull) throw PlanError(ST_UNSUPPORTED, "scratch need above 4 GiB");
 
-  out.program.assign(prog_bytes, 0);
+  if (kernel == KERNEL_STREAM_DICT_LDS) {
+    const Seq& dict = bld.seqs[bld.pipes[root].post[0].arg];
+    if (dict.count == 0) throw PlanError(ST_CORRUPT, "empty dictionary");
+    if (dict.loc == LOC_SCRATCH) {
+      // the LDS copy did not fit: gather from the dictionary inside the compressed bytes instead
+      for (size_t k = 0; k < bld.steps.size(); k++)
+        if (bld.steps[k].kind == S_MATERIALIZE && bld.steps[k].a[1] == bld.pipes[root].post[0].arg) {
+          bld.pipes[root].post[0].arg = bld.pipes[bld.steps[k].a[0]].a[0];
+          bld.steps.erase(bld.steps.begin() + k);
+          scratch = 0;
+          break;
+        }
+    }
+    if (bld.seqs[bld.pipes[root].post[0].arg].loc != LOC_LDS) kernel = KERNEL_STREAM_DICT_GLB;
+  }
+  const size_t n_steps_final = bld.bp_steps.size() + bld.steps.size();
+  const size_t prog_bytes_final = sizeof(ProgramHeader) + n_steps_final * sizeof(Step) +
+                                  bld.pipes.size() * sizeof(Pipe) + bld.seqs.size() * sizeof(Seq);
+  out.program.assign(prog_bytes_final, 0);
   uint8_t* p = out.program.data();
   ProgramHeader hdr{};
-  hdr.n_steps = (uint32_t)n_steps;
+  hdr.n_steps = (uint32_t)n_steps_final;
   hdr.n_bp_steps = (uint32_t)bld.bp_steps.size();
   hdr.n_pipes = (uint32_t)bld.pipes.size();
   hdr.n_seqs = (uint32_t)bld.seqs.size();
@@ -542,6 +575,7 @@ void build_program(const ColumnSource& src, BuiltProgram& out) {
   memcpy(p, bld.pipes.data(), bld.pipes.size() * sizeof(Pipe));
   p += bld.pipes.size() * sizeof(Pipe);
   memcpy(p, bld.seqs.data(), bld.seqs.size() * sizeof(Seq));
+  out.kernel = kernel;
   out.lds_bytes = table_base + (uint32_t)lds;
   out.scratch_bytes = (uint32_t)scratch;
   out.needed_bytes = bld.needed;

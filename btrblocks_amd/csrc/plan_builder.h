@@ -37,6 +37,7 @@ struct BuiltProgram {
   uint32_t scratch_bytes = 0;    // HBM scratch slice for tables that did not fit in LDS
   uint64_t needed_bytes = 0;     // compressed bytes the decoder actually reads
   uint32_t depth = 0;            // cascade depth of the tree
+  uint32_t kernel = 0;           // KERNEL_* that decodes this program
   std::string description;       // scheme tree in text form, e.g. "RLE(BP,BP)"
 };
 
