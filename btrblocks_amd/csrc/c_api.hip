@@ -542,7 +542,8 @@ btr_status btr_gpu_decode(btr_gpu_ctx* ctx, btr_gpu_plan* plan, void* hip_stream
   for (uint32_t kind = 0; kind < KERNEL_KINDS; kind++) {
     const size_t n = plan->kind_begin[kind + 1] - plan->kind_begin[kind];
     if (n == 0) continue;
-    hipLaunchKernelGGL(kernels[kind], dim3((unsigned)n), dim3(kBlockThreads), plan->kind_lds[kind],
+    hipLaunchKernelGGL(kernels[kind], dim3((unsigned)n), dim3(kind >= KERNEL_STREAM_NONE ? kStreamThreads : kBlockThreads),
+                       plan->kind_lds[kind],
                        (hipStream_t)hip_stream, plan->d_items, plan->d_order + plan->kind_begin[kind],
                        plan->d_programs, plan->d_status);
     HIP_TRY(hipGetLastError());

@@ -808,21 +808,26 @@ __device__ __forceinline__ void mat_int_bp(const Ctx& c, const IntEval& e, const
 }
 
 // ---- root step over a bit-packed stream, payload staged through an LDS ring ------------------------
-// The compressed stream is read from HBM exactly once, by 16-byte-per-lane direct-to-LDS buffer
-// loads (1 KiB per wave instruction), and everything else works out of LDS:
-//   wave 3 (loader)  keeps kRingAhead batches of 1024 payload words in flight into a ring of
-//                    kRingBatches batches;
-//   wave 0 (walker)  follows the group-header chain through the batch that has landed and writes
-//                    {word offset, header} per group into the index;
-//   waves 0-2        unpack the groups found in that batch from the ring and store the rows.
-// Two workgroup barriers per batch: A "batch t+1 has landed" (a group that starts in batch t may
-// run into batch t+1), B "the groups of batch t are indexed".
+// Used by the stream kernels (512 threads). The compressed stream is read from HBM exactly once,
+// by 16-byte-per-lane direct-to-LDS buffer loads (1 KiB per wave instruction); everything else
+// works out of LDS, with the waves of the workgroup in fixed roles:
+//   last wave (loader)  keeps kRingAhead batches of 1024 payload words in flight into a ring of
+//                       kRingBatches batches;
+//   wave 0 (walker)     follows the group-header chain through batch t+1 and writes {word offset,
+//                       header} per group into the index, while
+//   the other waves     unpack the groups that start in batch t from the ring, apply the post-op
+//                       and store the rows.
+// One workgroup barrier per batch: "batch t+1 has landed and the groups of batch t are indexed"
+// (a group that starts in batch t may run into batch t+1).
+constexpr u32 kStreamThreads = 512;
+constexpr u32 kStreamWaves = kStreamThreads / 64;
+constexpr u32 kUnpackWaves = kStreamWaves - 2;
 constexpr u32 kRingBatches = 4;  // power of two
-constexpr u32 kRingAhead = 3;    // batches issued ahead of the one being walked
+constexpr u32 kRingAhead = 3;    // batches issued ahead of the one being unpacked
 constexpr u32 kRingWords = kRingBatches * kBatchWords;
 static_assert(kRingWords * 4 == kStreamRingBytes, "ring size is shared with the plan compiler");
 
-__device__ __forceinline__ void barrier_lds() {  // LDS writes of this wave visible, then barrier
+__device__ __forceinline__ void barrier_lds() {  // LDS accesses of this wave complete, then barrier
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
@@ -841,17 +846,17 @@ __device__ __forceinline__ u32 ring_extract(u32 ring_off, u32 base_word, u32 b, 
 }
 
 constexpr u32 kRingGroupsPerIter = 4;
-constexpr u32 kRingWorkers = 3;
 
-// Groups [g_lo, g_hi) unpacked from the ring by waves 0..2; lane l produces values l and l+64.
+// Groups [g_lo, g_hi) unpacked from the ring by unpack wave `uw`; lane l produces values l and
+// l+64 of a group.
 template <u32 PS>
-__device__ __forceinline__ void ring_eval_groups(const Ctx& c, const IntEval& e, const Tab& out, u32 ring_off,
-                                                 u32 g_lo, u32 g_hi, u32 wave, u32& bad) {
+__device__ __forceinline__ void ring_eval_groups(const IntEval& e, u32* __restrict__ dst, u32 ring_off, u32 g_lo,
+                                                 u32 g_hi, u32 uw, u32& bad) {
   const u32 lane = threadIdx.x & 63;
   const BpView& bp = e.bp;
   const u32 k = lane & 31;
   const u32 upper_mask = lane >= 32 ? ~0u : 0u;
-  for (u32 g0 = g_lo + wave * kRingGroupsPerIter; g0 < g_hi; g0 += kRingWorkers * kRingGroupsPerIter) {
+  for (u32 g0 = g_lo + uw * kRingGroupsPerIter; g0 < g_hi; g0 += kUnpackWaves * kRingGroupsPerIter) {
     u32 v[kRingGroupsPerIter][2];
 #pragma unroll
     for (u32 j = 0; j < kRingGroupsPerIter; j++) {
@@ -869,27 +874,53 @@ __device__ __forceinline__ void ring_eval_groups(const Ctx& c, const IntEval& e,
     for (u32 j = 0; j < kRingGroupsPerIter; j++) {
       const u32 i = (g0 + j) * btrfmt::FBP_GROUP + lane;
       if (g0 + j < g_hi) {
-        if (c.debug & 16) {  // timing diagnostics: keep the values live without storing them
-          asm volatile("" ::"v"(v[j][0]), "v"(v[j][1]));
-          continue;
-        }
-        if (i < bp.rounded) tab_st32(out, i, v[j][0]);
-        if (i + 64 < bp.rounded) tab_st32(out, i + 64, v[j][1]);
+        if (i < bp.rounded) dst[i] = v[j][0];
+        if (i + 64 < bp.rounded) dst[i + 64] = v[j][1];
       }
     }
   }
 }
 
+// One batch of the header chain, read from the ring (same stepping as walker_advance).
+__device__ __forceinline__ void ring_walk_batch(u32 ring_off, u32 index_off, u32 t, u32 groups, u32& pos, u32& g,
+                                                u32& bad_hdr) {
+  const u32 lane = threadIdx.x & 63;
+  const u32 bb = t * kBatchWords;
+  const u32 slot = ring_off + (t & (kRingBatches - 1)) * (kBatchWords * 4);
+  u32 d[kWalkBatch];
+#pragma unroll
+  for (u32 k = 0; k < kWalkBatch; k++)
+    d[k] = group_lengths(*reinterpret_cast<const u32x4*>(lds_raw + slot + k * 1024 + lane * 16));
+  while (pos < bb + kBatchWords && g < groups) {
+    const u32 rel = pos - bb;
+    const u32 D = uniform(length_at(d, rel));
+    const u32 pj = rel + lane * D;
+    const bool inside = pj < kBatchWords;
+    const u32 dj = length_at(d, inside ? pj : rel);
+    const u64 ok = __ballot(inside && dj == D);
+    u32 m = (u32)__builtin_ctzll(~ok | (1ull << 63));
+    m = m == 63 && (ok >> 63) ? 64 : m;
+    m = m < groups - g ? m : groups - g;
+    if (lane < m) {
+      const u32 hv = ring_word(ring_off, bb + pj);
+      if ((hv & 0xC0C0C0C0u) || ((hv + 0x5F5F5F5Fu) & 0x80808080u)) bad_hdr = 1;  // widths must be <= 32
+      lds_st64(index_off + 8 * (g + lane), ((u64)hv << 32) | (bb + pj));
+    }
+    g = uniform(g + m);
+    pos = uniform(pos + m * D);
+  }
+}
+
 template <u32 PS>
-__device__ __forceinline__ void stream_int_bp(const Ctx& c, const Pipe& p, const IntEval& e, const Tab& out,
+__device__ __forceinline__ void stream_int_bp(const Ctx& c, const Pipe& p, const IntEval& e, u32* __restrict__ dst,
                                               u32 ring_off) {
   const u32 lane = threadIdx.x & 63, wave = uniform(threadIdx.x >> 6);
   const u32 W = uniform(p.a[1]), groups = uniform(p.a[5]);
   const u32 index_off = e.bp.index_off;
   const u32 batches = (W + kBatchWords - 1) / kBatchWords;
-  const u32 found_off = c.red_off + 32;  // LDS word: groups indexed so far
+  const u32 found_off = c.red_off + 32;  // two LDS words: groups indexed after batch t, slot t & 1
 
-  if (wave == kRingWorkers) {
+  if (wave == kStreamWaves - 1) {
     // ---- loader
     const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(e.bp.base, e.bp.bytes);
     auto issue = [&](u32 t) {
@@ -902,63 +933,56 @@ __device__ __forceinline__ void stream_int_bp(const Ctx& c, const Pipe& p, const
             (t * kBatchWords + 256 * k + 4 * lane) * 4, 0, 0, 0);
     };
     for (u32 t = 0; t < kRingAhead; t++) issue(t);
+    // batches 0 and 1 landed (only batch 2 may still be in flight), then the start barrier
+    if (batches > 2)
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
     for (u32 t = 0; t < batches; t++) {
-      // batches t and t+1 must have landed; at most one younger batch (t+2) may stay in flight
+      // before barrier t: batch t+1 landed; at most batch t+2 stays in flight
       if (t + 2 < batches)
         asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
       else
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();  // A_t
-      issue(t + kRingAhead);
-      __builtin_amdgcn_s_barrier();  // B_t
+      __builtin_amdgcn_s_barrier();
+      issue(t + kRingAhead);  // its slot held batch t-1, fully consumed before this barrier
     }
-  } else {
-    // ---- walker (wave 0) and unpackers (waves 0..2)
-    u32 pos = 1, g = 0, bad_hdr = 0, bad = 0;
+  } else if (wave == 0) {
+    // ---- walker: batch 0 before barrier 0, then batch t+1 during iteration t
+    u32 pos = 1, g = 0, bad_hdr = 0;
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    ring_walk_batch(ring_off, index_off, 0, groups, pos, g, bad_hdr);
+    if (lane == 0) lds_st32(found_off, g);
     for (u32 t = 0; t < batches; t++) {
-      const u32 g_before = g;
-      __builtin_amdgcn_s_barrier();  // A_t
-      asm volatile("" ::: "memory");
-      if (wave == 0 && !(c.debug & 4)) {
-        const u32 bb = t * kBatchWords;
-        const u32 slot = ring_off + (t & (kRingBatches - 1)) * (kBatchWords * 4);
-        u32 d[kWalkBatch];
-#pragma unroll
-        for (u32 k = 0; k < kWalkBatch; k++)
-          d[k] = group_lengths(*reinterpret_cast<const u32x4*>(lds_raw + slot + k * 1024 + lane * 16));
-        while (pos < bb + kBatchWords && g < groups) {  // same stepping as walker_advance
-          const u32 rel = pos - bb;
-          const u32 D = uniform(length_at(d, rel));
-          const u32 pj = rel + lane * D;
-          const bool inside = pj < kBatchWords;
-          const u32 dj = length_at(d, inside ? pj : rel);
-          const u64 ok = __ballot(inside && dj == D);
-          u32 m = (u32)__builtin_ctzll(~ok | (1ull << 63));
-          m = m == 63 && (ok >> 63) ? 64 : m;
-          m = m < groups - g ? m : groups - g;
-          if (lane < m) {
-            const u32 hv = ring_word(ring_off, bb + pj);
-            if ((hv & 0xC0C0C0C0u) || ((hv + 0x5F5F5F5Fu) & 0x80808080u)) bad_hdr = 1;
-            lds_st64(index_off + 8 * (g + lane), ((u64)hv << 32) | (bb + pj));
-          }
-          g = uniform(g + m);
-          pos = uniform(pos + m * D);
-        }
-        if (lane == 0) lds_st32(found_off, g);
+      barrier_lds();
+      if (t + 1 < batches) {
+        ring_walk_batch(ring_off, index_off, t + 1, groups, pos, g, bad_hdr);
+        if (lane == 0) lds_st32(found_off + 4 * ((t + 1) & 1), g);
       }
-      barrier_lds();  // B_t
-      g = uniform(lds32(found_off));
-      if (c.debug & 4) g = (t + 1) * 21 < groups ? (t + 1) * 21 : groups;  // timing diagnostics
-      if (!(c.debug & 8)) ring_eval_groups<PS>(c, e, out, ring_off, g_before, g, wave, bad);
+    }
+    // sentinel, flags and the VariableByte tail (read from global memory)
+    walker_finish(WalkEnd{e.bp.base, W, e.bp.rounded, groups, index_off, pos, g, __any(bad_hdr) ? 1u : 0u}, c, p);
+  } else {
+    // ---- unpackers: the groups that start in batch t, during iteration t
+    u32 g_lo = 0, bad = 0;
+    __builtin_amdgcn_s_barrier();
+    for (u32 t = 0; t < batches; t++) {
+      barrier_lds();
+      const u32 g_hi = uniform(lds32(found_off + 4 * (t & 1)));
+      ring_eval_groups<PS>(e, dst, ring_off, g_lo, g_hi, wave - 1, bad);
+      g_lo = g_hi;
     }
     report(c, bad);
-    if (wave == 0) {
-      // sentinel, flags and the VariableByte tail (read from global memory)
-      walker_finish(WalkEnd{e.bp.base, W, e.bp.rounded, groups, index_off, pos, g, __any(bad_hdr) ? 1u : 0u}, c, p);
-    }
   }
   __syncthreads();
-  eval_bp_tail<PS>(c, e, out, e.count);
+  {
+    u32 bad = 0;
+    for (u32 i = e.bp.rounded + threadIdx.x; i < e.count; i += kStreamThreads)
+      dst[i] = apply_posts<PS>(e, lds32(e.bp.tail_off + 4 * ((i - e.bp.rounded) & 31)), bad);
+    report(c, bad);
+  }
 }
 
 template <u32 BASE, u32 IA, u32 IB, u32 IPS>
@@ -1186,12 +1210,13 @@ __device__ void write_nullmap(const Ctx& c, const Step& s) {
 }
 
 // Copies the work item's program into LDS and sets up the workgroup context.
+template <u32 THREADS>
 __device__ __forceinline__ ProgramHeader load_program(const WorkItem& it, u32 item, const u8* __restrict__ programs,
                                                       u32* __restrict__ status, Ctx& c) {
   const u32 tid = threadIdx.x;
   {
     const u32* prog = reinterpret_cast<const u32*>(programs + it.prog_off);
-    for (u32 o = tid; o < it.prog_bytes / 4; o += kBlockThreads) lds_st32(4 * o, prog[o]);
+    for (u32 o = tid; o < it.prog_bytes / 4; o += THREADS) lds_st32(4 * o, prog[o]);
     if (tid == 0) status[item] = 0;  // later raise() calls are ordered behind the barrier
   }
   __syncthreads();
@@ -1222,18 +1247,18 @@ __device__ __forceinline__ void stream_block(const WorkItem* __restrict__ items,
   const u32 item = order[blockIdx.x];
   const WorkItem it = items[item];
   Ctx c;
-  const ProgramHeader hdr = load_program(it, item, programs, status, c);
+  const ProgramHeader hdr = load_program<kStreamThreads>(it, item, programs, status, c);
   for (u32 s = 0; s + 1 < hdr.n_steps; s++) {  // dictionary copies: a bare source sequence -> LDS
     const Step& st = step_at(c, s);
     const Tab from = resolve_tab(c, uniform(pipe_at(c, uniform(st.a[0])).a[0]));
     const Tab to = resolve_tab(c, uniform(st.a[1]));
-    for (u32 i = threadIdx.x; i < to.count; i += kBlockThreads) lds_st32(to.lds + 4 * i, ldg32(from.g + 4ull * i));
+    for (u32 i = threadIdx.x; i < to.count; i += kStreamThreads) lds_st32(to.lds + 4 * i, ldg32(from.g + 4ull * i));
   }
   __syncthreads();
   const Step& root = step_at(c, hdr.n_steps - 1);
   const u32 pipe_id = uniform(root.a[0]);
   const IntEval e = resolve_int(c, pipe_id);
-  stream_int_bp<PS>(c, pipe_at(c, pipe_id), e, resolve_tab(c, uniform(root.a[1])), seq_lds(c, uniform(root.a[2])));
+  stream_int_bp<PS>(c, pipe_at(c, pipe_id), e, reinterpret_cast<u32*>(c.dst), seq_lds(c, uniform(root.a[2])));
 }
 
 template <bool DOUBLE_KERNEL>
@@ -1243,7 +1268,7 @@ __device__ inline void decode_block(const WorkItem* __restrict__ items, const u3
   const WorkItem it = items[item];
   const u32 tid = threadIdx.x;
   Ctx c;
-  const ProgramHeader hdr = load_program(it, item, programs, status, c);
+  const ProgramHeader hdr = load_program<kBlockThreads>(it, item, programs, status, c);
 
   // bit-unpack indexes: one stream per wave, streams in parallel
   if (!(it.debug_flags & 1))
@@ -1285,22 +1310,22 @@ btr_decode_dbl_kernel(const WorkItem* __restrict__ items, const u32* __restrict_
 }
 
 // Streamed bit-packed integer roots, one kernel per post-op signature (plan.h: KERNEL_STREAM_*).
-extern "C" __global__ void __launch_bounds__(kBlockThreads)
+extern "C" __global__ void __launch_bounds__(kStreamThreads)
 btr_stream_none_kernel(const WorkItem* __restrict__ items, const u32* __restrict__ order,
                        const u8* __restrict__ programs, u32* __restrict__ status) {
   stream_block<PS_NONE>(items, order, programs, status);
 }
-extern "C" __global__ void __launch_bounds__(kBlockThreads)
+extern "C" __global__ void __launch_bounds__(kStreamThreads)
 btr_stream_add_kernel(const WorkItem* __restrict__ items, const u32* __restrict__ order,
                       const u8* __restrict__ programs, u32* __restrict__ status) {
   stream_block<PS_ADD>(items, order, programs, status);
 }
-extern "C" __global__ void __launch_bounds__(kBlockThreads)
+extern "C" __global__ void __launch_bounds__(kStreamThreads)
 btr_stream_dict_lds_kernel(const WorkItem* __restrict__ items, const u32* __restrict__ order,
                            const u8* __restrict__ programs, u32* __restrict__ status) {
   stream_block<PS_DICT_LDS>(items, order, programs, status);
 }
-extern "C" __global__ void __launch_bounds__(kBlockThreads)
+extern "C" __global__ void __launch_bounds__(kStreamThreads)
 btr_stream_dict_glb_kernel(const WorkItem* __restrict__ items, const u32* __restrict__ order,
                            const u8* __restrict__ programs, u32* __restrict__ status) {
   stream_block<PS_DICT_GLB>(items, order, programs, status);
