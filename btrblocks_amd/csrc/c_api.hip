@@ -407,10 +407,16 @@ btr_status btr_gpu_ctx_create(int device, btr_gpu_ctx** out) {
   if (device < 0 || device >= count) return fail(BTR_ERR_INVALID_ARGUMENT, "device index out of range");
   DeviceGuard guard(device);
   if (!guard.ok) return fail(BTR_ERR_DEVICE, "hipSetDevice failed");
-  hipFuncAttributes attr;
-  e = hipFuncGetAttributes(&attr, (const void*)btr_decode_int_kernel);
-  if (e == hipSuccess) e = hipFuncGetAttributes(&attr, (const void*)btr_decode_dbl_kernel);
-  if (e == hipSuccess) e = hipFuncGetAttributes(&attr, (const void*)btr_stream_dict_lds_kernel);
+  const void* kernels[] = {(const void*)btr_decode_int_kernel,      (const void*)btr_decode_dbl_kernel,
+                           (const void*)btr_stream_none_kernel,     (const void*)btr_stream_add_kernel,
+                           (const void*)btr_stream_dict_lds_kernel, (const void*)btr_stream_dict_glb_kernel};
+  for (const void* k : kernels) {
+    hipFuncAttributes attr;
+    e = hipFuncGetAttributes(&attr, k);
+    // blocks with many rows need more than the default 64 KiB of dynamic LDS
+    if (e == hipSuccess) e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsCapBytes);
+    if (e != hipSuccess) break;
+  }
   if (e != hipSuccess)
     return fail(BTR_ERR_DEVICE, std::string("decode kernel has no code object for this device (built for gfx950): ") +
                                     hipGetErrorString(e));

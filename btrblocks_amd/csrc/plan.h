@@ -143,6 +143,6 @@ enum : uint32_t {
 
 constexpr uint32_t kBlockThreads = 256;
 constexpr uint32_t kStreamRingBytes = 16 * 1024;  // LDS ring of the streamed root step (4 batches of 1024 words)
-constexpr uint32_t kLdsCapBytes = 64 * 1024;
+constexpr uint32_t kLdsCapBytes = 160 * 1024;  // all of a gfx950 CU's LDS; typical chunks need 5-40 KiB
 
 }  // namespace btrplan
