@@ -132,6 +132,7 @@ struct btr_gpu_plan {
   size_t kind_begin[KERNEL_KINDS + 1] = {};
   uint32_t kind_lds[KERNEL_KINDS] = {};  // dynamic LDS per launch
   uint8_t* d_scratch = nullptr;
+  uint32_t* d_debug = nullptr;  // BTR_DEBUG_FLAGS & 8: kDebugSlots timestamps per work item
   btr_plan_stats stats{};
   std::vector<uint32_t> h_status;
 };
@@ -178,6 +179,13 @@ btr_status finish_plan(btr_gpu_ctx* ctx, std::vector<WorkItem>& items, std::vect
   }
   for (size_t i = 0; i < items.size(); i++)
     items[i].scratch = progs[i].scratch_bytes ? (uint64_t)(uintptr_t)plan->d_scratch + items[i].scratch : 0;
+  if ((debug_flags & 8) && !items.empty()) {
+    if ((e = hipMalloc((void**)&plan->d_debug, items.size() * kDebugSlots * 4)) != hipSuccess)
+      return cleanup(hip_fail(e, "hipMalloc(debug)"));
+    (void)hipMemset(plan->d_debug, 0, items.size() * kDebugSlots * 4);
+  }
+  for (size_t i = 0; i < items.size(); i++)
+    items[i].debug_buf = plan->d_debug ? (uint64_t)(uintptr_t)(plan->d_debug + i * kDebugSlots) : 0;
   if (!items.empty()) {
     if ((e = hipMalloc((void**)&plan->d_items, items.size() * sizeof(WorkItem))) != hipSuccess)
       return cleanup(hip_fail(e, "hipMalloc(items)"));
@@ -525,6 +533,7 @@ void btr_gpu_plan_destroy(btr_gpu_plan* plan) {
   if (plan->d_items) (void)hipFree(plan->d_items);
   if (plan->d_programs) (void)hipFree(plan->d_programs);
   if (plan->d_status) (void)hipFree(plan->d_status);
+  if (plan->d_debug) (void)hipFree(plan->d_debug);
   if (plan->d_order) (void)hipFree(plan->d_order);
   if (plan->d_scratch) (void)hipFree(plan->d_scratch);
   delete plan;
@@ -565,6 +574,32 @@ btr_status btr_gpu_plan_check(btr_gpu_ctx* ctx, btr_gpu_plan* plan, void* hip_st
   plan->h_status.resize(plan->n_items);
   if (plan->n_items)
     HIP_TRY(hipMemcpy(plan->h_status.data(), plan->d_status, plan->n_items * 4, hipMemcpyDeviceToHost));
+  if (plan->d_debug && plan->n_items) {
+    // timing diagnostics: per slot, mean offset from the item's first stamp; and when items started
+    std::vector<uint32_t> ts(plan->n_items * kDebugSlots);
+    HIP_TRY(hipMemcpy(ts.data(), plan->d_debug, ts.size() * 4, hipMemcpyDeviceToHost));
+    uint32_t t0 = ~0u;
+    for (size_t i = 0; i < plan->n_items; i++)
+      if (ts[i * kDebugSlots]) t0 = std::min(t0, ts[i * kDebugSlots]);
+    fprintf(stderr, "[btr debug] %zu items; mean us since item start per stamp:", plan->n_items);
+    for (uint32_t k = 1; k < kDebugSlots; k++) {
+      double sum = 0;
+      size_t cnt = 0;
+      for (size_t i = 0; i < plan->n_items; i++)
+        if (ts[i * kDebugSlots] && ts[i * kDebugSlots + k]) {
+          sum += (double)(uint32_t)(ts[i * kDebugSlots + k] - ts[i * kDebugSlots]) * 0.01;
+          cnt++;
+        }
+      if (cnt) fprintf(stderr, " [%u] %.2f", k, sum / cnt);
+    }
+    std::vector<uint32_t> starts;
+    for (size_t i = 0; i < plan->n_items; i++)
+      if (ts[i * kDebugSlots]) starts.push_back(ts[i * kDebugSlots] - t0);
+    std::sort(starts.begin(), starts.end());
+    fprintf(stderr, "\n[btr debug] item start times (us), deciles:");
+    for (int d = 0; d <= 10; d++) fprintf(stderr, " %.1f", starts[(starts.size() - 1) * d / 10] * 0.01);
+    fprintf(stderr, "\n");
+  }
   uint32_t any = 0;
   uint64_t first = ~0ull;
   for (size_t i = 0; i < plan->n_items; i++) {

@@ -68,29 +68,29 @@ __constant__ double kFractions[23] = {
 };
 
 // ---- small loads ---------------------------------------------------------------------------
-__device__ inline u32 ldg32(const u8* p) {  // any byte alignment
+__device__ __forceinline__ u32 ldg32(const u8* p) {  // any byte alignment
   u32 v;
   __builtin_memcpy(&v, p, 4);
   return v;
 }
-__device__ inline u64 ldg64(const u8* p) {
+__device__ __forceinline__ u64 ldg64(const u8* p) {
   u64 v;
   __builtin_memcpy(&v, p, 8);
   return v;
 }
-__device__ inline u32 ldg16(const u8* p) {
+__device__ __forceinline__ u32 ldg16(const u8* p) {
   u16 v;
   __builtin_memcpy(&v, p, 2);
   return v;
 }
-__device__ inline u32 lds32(u32 off) { return *reinterpret_cast<const u32*>(lds_raw + off); }
-__device__ inline u64 lds64(u32 off) { return *reinterpret_cast<const u64*>(lds_raw + off); }
-__device__ inline void lds_st32(u32 off, u32 v) { *reinterpret_cast<u32*>(lds_raw + off) = v; }
-__device__ inline void lds_st64(u32 off, u64 v) { *reinterpret_cast<u64*>(lds_raw + off) = v; }
+__device__ __forceinline__ u32 lds32(u32 off) { return *reinterpret_cast<const u32*>(lds_raw + off); }
+__device__ __forceinline__ u64 lds64(u32 off) { return *reinterpret_cast<const u64*>(lds_raw + off); }
+__device__ __forceinline__ void lds_st32(u32 off, u32 v) { *reinterpret_cast<u32*>(lds_raw + off) = v; }
+__device__ __forceinline__ void lds_st64(u32 off, u64 v) { *reinterpret_cast<u64*>(lds_raw + off) = v; }
 // Values read from the program tables in LDS are the same in every lane, but the compiler must
 // be told: readfirstlane moves them to scalar registers so that loops over them stay scalar.
-__device__ inline u32 uniform(u32 v) { return __builtin_amdgcn_readfirstlane(v); }
-__device__ inline const u8* uniform_ptr(const u8* p) {
+__device__ __forceinline__ u32 uniform(u32 v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ const u8* uniform_ptr(const u8* p) {
   const u64 v = reinterpret_cast<u64>(p);
   return reinterpret_cast<const u8*>(((u64)uniform((u32)(v >> 32)) << 32) | uniform((u32)v));
 }
@@ -99,7 +99,7 @@ typedef u32 u32x2 __attribute__((ext_vector_type(2)));
 typedef u32 u32x4 __attribute__((ext_vector_type(4)));
 // Raw buffer descriptor over `bytes` bytes at p: loads past the end return 0 instead of faulting,
 // so payload reads need no clamping.
-__device__ inline __amdgpu_buffer_rsrc_t make_rsrc(const void* p, u32 bytes) {
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, u32 bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
 }
 
@@ -116,17 +116,22 @@ struct Ctx {
   u32 debug;                           // WorkItem::debug_flags
 };
 
-__device__ inline const Step& step_at(const Ctx& c, u32 i) {
+__device__ __forceinline__ const Step& step_at(const Ctx& c, u32 i) {
   return *reinterpret_cast<const Step*>(lds_raw + c.steps_off + i * sizeof(Step));
 }
-__device__ inline const Pipe& pipe_at(const Ctx& c, u32 i) {
+__device__ __forceinline__ const Pipe& pipe_at(const Ctx& c, u32 i) {
   return *reinterpret_cast<const Pipe*>(lds_raw + c.pipes_off + i * sizeof(Pipe));
 }
-__device__ inline const Seq& seq_at(const Ctx& c, u32 i) {
+__device__ __forceinline__ const Seq& seq_at(const Ctx& c, u32 i) {
   return *reinterpret_cast<const Seq*>(lds_raw + c.seqs_off + i * sizeof(Seq));
 }
-__device__ inline void raise(const Ctx& c, u32 bits) { atomicOr(c.status, bits); }
-__device__ inline u32 seq_lds(const Ctx& c, u32 seq_id) { return c.table_base + uniform(seq_at(c, seq_id).off); }
+__device__ __forceinline__ void raise(const Ctx& c, u32 bits) { atomicOr(c.status, bits); }
+// Diagnostics: timestamp `slot` of this work item (constant 100 MHz clock), thread 0 only.
+__device__ __forceinline__ void stamp(const WorkItem& it, u32 slot) {
+  if ((it.debug_flags & 8) && threadIdx.x == 0 && slot < kDebugSlots)
+    reinterpret_cast<u32*>(it.debug_buf)[slot] = (u32)wall_clock64();
+}
+__device__ __forceinline__ u32 seq_lds(const Ctx& c, u32 seq_id) { return c.table_base + uniform(seq_at(c, seq_id).off); }
 
 // A resolved sequence: LDS byte offset or global pointer.
 struct Tab {
@@ -159,27 +164,27 @@ __device__ __forceinline__ Tab resolve_tab(const Ctx& c, u32 seq_id) {
   }
   return t;
 }
-__device__ inline u32 tab_ld32(const Tab& t, u32 i) {
+__device__ __forceinline__ u32 tab_ld32(const Tab& t, u32 i) {
   if (t.loc == LOC_LDS) return lds32(t.lds + 4 * i);
   return ldg32(t.g + 4ull * i);
 }
-__device__ inline u64 tab_ld64(const Tab& t, u32 i) {
+__device__ __forceinline__ u64 tab_ld64(const Tab& t, u32 i) {
   if (t.loc == LOC_LDS) return lds64(t.lds + 8 * i);
   return ldg64(t.g + 8ull * i);
 }
-__device__ inline u32 tab_ld_small(const Tab& t, u32 i) {  // esize 1, 2 or 4
+__device__ __forceinline__ u32 tab_ld_small(const Tab& t, u32 i) {  // esize 1, 2 or 4
   if (t.esize == 4) return tab_ld32(t, i);
   if (t.loc == LOC_LDS)
     return t.esize == 1 ? lds_raw[t.lds + i] : *reinterpret_cast<const u16*>(lds_raw + t.lds + 2 * i);
   return t.esize == 1 ? (u32)t.g[i] : ldg16(t.g + 2ull * i);
 }
-__device__ inline void tab_st32(const Tab& t, u32 i, u32 v) {
+__device__ __forceinline__ void tab_st32(const Tab& t, u32 i, u32 v) {
   if (t.loc == LOC_LDS)
     lds_st32(t.lds + 4 * i, v);
   else
     *reinterpret_cast<u32*>(const_cast<u8*>(t.g) + 4ull * i) = v;  // scratch and output are aligned
 }
-__device__ inline void tab_st64(const Tab& t, u32 i, u64 v) {
+__device__ __forceinline__ void tab_st64(const Tab& t, u32 i, u64 v) {
   if (t.loc == LOC_LDS)
     lds_st64(t.lds + 8 * i, v);
   else
@@ -192,14 +197,14 @@ struct RankView {
   u32 bits_off, rank_off;
 };
 // set bits strictly below row i, and whether row i itself is set
-__device__ inline u32 rank_lt(const RankView& r, u32 i, bool* member) {
+__device__ __forceinline__ u32 rank_lt(const RankView& r, u32 i, bool* member) {
   const u32 w = i >> 6, p = i & 63;
   const u64 word = lds64(r.bits_off + 8 * w);
   *member = (word >> p) & 1;
   return lds32(r.rank_off + 4 * w) + __popcll(word & ((1ull << p) - 1));
 }
 // set bits at or below row i
-__device__ inline u32 rank_le(const RankView& r, u32 i) {
+__device__ __forceinline__ u32 rank_le(const RankView& r, u32 i) {
   const u32 w = i >> 6, p = i & 63;
   const u64 word = lds64(r.bits_off + 8 * w);
   return lds32(r.rank_off + 4 * w) + __popcll(word & ((2ull << p) - 1));
@@ -524,7 +529,7 @@ __device__ __forceinline__ u64 eval_dbl(const DblEval& e, u32 i, u32& bad) {
 }
 
 // ---- block-wide exclusive scan of one value per thread ------------------------------------------
-__device__ inline u32 block_exclusive_scan(const Ctx& c, u32 v, u32* total) {
+__device__ __forceinline__ u32 block_exclusive_scan(const Ctx& c, u32 v, u32* total) {
   const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   u32 incl = v;
 #pragma unroll
@@ -552,7 +557,7 @@ __device__ inline u32 block_exclusive_scan(const Ctx& c, u32 v, u32* total) {
 // Every word is turned into "group length if this word were a header" (1 + the sum of its four
 // width bytes); the chain of real headers is then followed through the batch (see the loop).
 // Group start positions go to the LDS index; header words are gathered in parallel afterwards.
-__device__ inline u32 group_lengths(const u32x4& w) {
+__device__ __forceinline__ u32 group_lengths(const u32x4& w) {
   auto glen = [](u32 x) {
     const u32 s = 1 + __builtin_amdgcn_sad_u8(x, 0u, 0u);
     return s > 255 ? 255u : s;
@@ -564,7 +569,7 @@ constexpr u32 kWalkBatch = 4;  // 256-word windows per batch (1024 words, 16 per
 
 // "Group length if the word at batch position p were a header", gathered from the lane that
 // holds it: lane (p/4)%64 keeps byte p%4 of window p/256.
-__device__ inline u32 length_at(const u32 (&d)[kWalkBatch], u32 p) {
+__device__ __forceinline__ u32 length_at(const u32 (&d)[kWalkBatch], u32 p) {
   const u32 src_lane = ((p >> 2) & 63) << 2;
   u32 v = __builtin_amdgcn_ds_bpermute(src_lane, d[0]);
 #pragma unroll
@@ -575,13 +580,13 @@ __device__ inline u32 length_at(const u32 (&d)[kWalkBatch], u32 p) {
   return (v >> (8 * (p & 3))) & 0xFF;
 }
 
-// Resumable walk state, kept in the registers of the walking wave.
+// Walk state, kept in the registers of the walking wave.
 struct Walker {
   const u8* base;
   u32 W, rounded, groups, index_off;
   u32 pos, g, bb;  // next header position, groups found, first word of the current batch
-  u32 gathered;    // groups whose header word has been fetched into the index
   u32 bad;
+  u32 tail_word;          // word max(W, 64) - 64 + lane of the stream: covers any VariableByte tail
   u32 d[kWalkBatch];      // packed group lengths of the current batch
   u32x4 nxt[kWalkBatch];  // next batch, in flight
 };
@@ -589,6 +594,13 @@ constexpr u32 kBatchWords = 256 * kWalkBatch;
 
 __device__ __forceinline__ u32x4 load_window(__amdgpu_buffer_rsrc_t rsrc, u32 first_word, u32 lane) {
   return __builtin_amdgcn_raw_buffer_load_b128(rsrc, (first_word + 4 * lane) * 4, 0, 0);  // past the end: 0
+}
+
+// The last 64 words of a stream, one per lane (lane l: word max(W, 64) - 64 + l). Loaded before
+// the walk so that the tail decode at its end does not wait for memory.
+__device__ __forceinline__ u32 load_tail_words(__amdgpu_buffer_rsrc_t rsrc, u32 W) {
+  const u32 first = W > 64 ? W - 64 : 0;
+  return __builtin_amdgcn_raw_buffer_load_b32(rsrc, (first + (threadIdx.x & 63)) * 4, 0, 0);
 }
 
 __device__ __forceinline__ void walker_init(Walker& w, const Ctx& c, const Pipe& p) {
@@ -604,19 +616,19 @@ __device__ __forceinline__ void walker_init(Walker& w, const Ctx& c, const Pipe&
   for (u32 k = 0; k < kWalkBatch; k++) cur[k] = load_window(rsrc, 256 * k, lane);
 #pragma unroll
   for (u32 k = 0; k < kWalkBatch; k++) w.nxt[k] = load_window(rsrc, kBatchWords + 256 * k, lane);
+  w.tail_word = load_tail_words(rsrc, w.W);
 #pragma unroll
   for (u32 k = 0; k < kWalkBatch; k++) w.d[k] = group_lengths(cur[k]);
   w.pos = 1;
-  w.g = w.bb = w.gathered = w.bad = 0;
+  w.g = w.bb = w.bad = 0;
 }
 
-// Finds group starts until `until` groups are known (or the stream ends) and completes their
-// index entries {word offset, header}.
-__device__ __forceinline__ void walker_advance(Walker& w, u32 until) {
+// Finds the start of every group (or stops where the stream ends), then completes the index
+// entries {word offset, header}.
+__device__ __forceinline__ void walker_run(Walker& w) {
   const u32 lane = threadIdx.x & 63;
   const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(w.base, w.W * 4);
-  until = until < w.groups ? until : w.groups;
-  while (w.g < until) {
+  while (w.g < w.groups) {
     if (w.pos >= w.bb + kBatchWords) {  // move to the next batch
       if (w.bb + kBatchWords >= w.W) break;
       w.bb += kBatchWords;
@@ -639,26 +651,25 @@ __device__ __forceinline__ void walker_advance(Walker& w, u32 until) {
     const u64 ok = __ballot(inside && dj == D);
     u32 m = (u32)__builtin_ctzll(~ok | (1ull << 63));
     m = m == 63 && (ok >> 63) ? 64 : m;
-    m = m < until - w.g ? m : until - w.g;
+    m = m < w.groups - w.g ? m : w.groups - w.g;
     if (lane < m) lds_st32(w.index_off + 8 * (w.g + lane), w.bb + pj);
     w.g = uniform(w.g + m);
     w.pos = uniform(w.pos + m * D);
   }
-  // fetch and validate the header word of every new group (every width byte must be <= 32)
-  for (u32 gg = w.gathered + lane; gg < w.g; gg += 64) {
+  // fetch and validate the header word of every group (every width byte must be <= 32)
+  for (u32 gg = lane; gg < w.g; gg += 64) {
     const u32 gp = lds32(w.index_off + 8 * gg);
     const u32 hv = __builtin_amdgcn_raw_buffer_load_b32(rsrc, gp * 4, 0, 0);
     if ((hv & 0xC0C0C0C0u) || ((hv + 0x5F5F5F5Fu) & 0x80808080u)) w.bad = 1;
     lds_st32(w.index_off + 8 * gg + 4, hv);
   }
-  w.gathered = w.g;
 }
 
 // After the last group: flags, the end-of-packing sentinel and the VariableByte tail (fewer
 // than 32 values: 7 bits per byte, low group first, a set top bit ends a value).
 struct WalkEnd {
-  const u8* base;
   u32 W, rounded, groups, index_off, pos, g, bad;
+  u32 tail_word;  // load_tail_words()
 };
 __device__ __forceinline__ void walker_finish(const WalkEnd& w, const Ctx& c, const Pipe& p) {
   const u32 lane = threadIdx.x & 63;
@@ -673,16 +684,18 @@ __device__ __forceinline__ void walker_finish(const WalkEnd& w, const Ctx& c, co
   if (bad) raise(c, ST_BP_HEADER);
   const u32 tail_seq = uniform(p.a[4]);
   if (tail_seq != NONE) {
-    const u32* words = reinterpret_cast<const u32*>(w.base);
     const u32 tail_off = seq_lds(c, tail_seq);
     const u32 count = uniform(p.count);
     const u32 stream_values = uniform(p.base) == B_DBP ? 2 * count : count;
     const u32 expect = stream_values - w.rounded;
-    const u32 tail_words = w.W - pos < 64 ? w.W - pos : 64;
-    const u32 tw = lane < tail_words ? words[pos + lane] : 0;
+    // a tail of more than 64 words cannot be one (31 values of at most 5 bytes): its first 64
+    // words are skipped and the count check below reports it
+    const u32 first = w.W > 64 ? w.W - 64 : 0;
+    const u32 skip = pos > first ? pos - first : 0;  // lanes in front of the tail
+    const u32 tail_words = w.W - first - skip;
     u32 v = 0, shift = 0, produced = 0;
     for (u32 bi = 0; bi < tail_words * 4; bi++) {
-      const u32 wv = __builtin_amdgcn_readlane(tw, bi >> 2);
+      const u32 wv = __builtin_amdgcn_readlane(w.tail_word, skip + (bi >> 2));
       const u32 ch = (wv >> ((bi & 3) * 8)) & 0xFF;
       v += (ch & 127) << (shift & 31);
       shift += 7;
@@ -693,15 +706,15 @@ __device__ __forceinline__ void walker_finish(const WalkEnd& w, const Ctx& c, co
         shift = 0;
       }
     }
-    if (produced != expect && lane == 0) raise(c, ST_BP_TAIL);
+    if ((produced != expect || pos < first) && lane == 0) raise(c, ST_BP_TAIL);
   }
 }
 
-__device__ void bp_index_wave(const Ctx& c, const Pipe& p) {
+__device__ __forceinline__ void bp_index_wave(const Ctx& c, const Pipe& p) {
   Walker w;
   walker_init(w, c, p);
-  walker_advance(w, w.groups);
-  walker_finish(WalkEnd{w.base, w.W, w.rounded, w.groups, w.index_off, w.pos, w.g, w.bad}, c, p);
+  walker_run(w);
+  walker_finish(WalkEnd{w.W, w.rounded, w.groups, w.index_off, w.pos, w.g, w.bad, w.tail_word}, c, p);
 }
 
 // ---- step: materialize a pipe into a sequence ----------------------------------------------------
@@ -730,6 +743,108 @@ __device__ __forceinline__ void mat_int(const Ctx& c, const IntEval& e, const Ta
     }
   }
   report(c, bad);
+}
+
+// ---- four consecutive rows per lane -----------------------------------------------------------
+// Root steps of table-driven bases (fill, copy, run expansion, exception patching) write 16 bytes
+// per lane: one bitmap word and one rank lookup serve four rows, and a wave stores 1 KiB per
+// instruction.
+template <u32 BASE>
+__device__ __forceinline__ u32x4 eval_int4_base(const IntEval& e, u32 i, __amdgpu_buffer_rsrc_t seq_rsrc) {
+  u32x4 v;
+  if (BASE == B_ONE) {
+    v.x = v.y = v.z = v.w = e.k0;
+  } else if (BASE == B_SEQ) {
+    v = __builtin_amdgcn_raw_buffer_load_b128(seq_rsrc, i * 4, 0, 0);
+  } else if (BASE == B_RLE) {
+    // rows i..i+3 share a bitmap word (i is a multiple of 4): run index of row i from the rank
+    // table, the next three advance by their start flags (templated/RLE.hpp:164-191)
+    const u32 w = i >> 6, p = i & 63;
+    const u64 word = lds64(e.rk.bits_off + 8 * w);
+    const u32 r = lds32(e.rk.rank_off + 4 * w) + __popcll(word & ((2ull << p) - 1));
+    const u32 m = (u32)(word >> (p + 1));
+    const u32 last = e.tab.count - 1;
+    u32 r0 = r ? r - 1 : 0;
+    u32 r1 = r0 + (m & 1), r2 = r1 + ((m >> 1) & 1), r3 = r2 + ((m >> 2) & 1);
+    r0 = r0 < last ? r0 : last;
+    r1 = r1 < last ? r1 : last;
+    r2 = r2 < last ? r2 : last;
+    r3 = r3 < last ? r3 : last;
+    v.x = tab_ld32(e.tab, r0);
+    v.y = tab_ld32(e.tab, r1);
+    v.z = tab_ld32(e.tab, r2);
+    v.w = tab_ld32(e.tab, r3);
+  } else {  // B_FREQ: top value unless the row is a bitmap member (templated/Frequency.hpp:118-135)
+    const u32 w = i >> 6, p = i & 63;
+    const u64 word = lds64(e.rk.bits_off + 8 * w);
+    const u32 m = (u32)(word >> p) & 15;
+    v.x = v.y = v.z = v.w = e.k0;
+    if (m) {
+      const u32 last = e.tab.count - 1;
+      u32 r = lds32(e.rk.rank_off + 4 * w) + __popcll(word & ((1ull << p) - 1));
+      if (m & 1) v.x = tab_ld32(e.tab, r < last ? r : last);
+      r += m & 1;
+      if (m & 2) v.y = tab_ld32(e.tab, r < last ? r : last);
+      r += (m >> 1) & 1;
+      if (m & 4) v.z = tab_ld32(e.tab, r < last ? r : last);
+      r += (m >> 2) & 1;
+      if (m & 8) v.w = tab_ld32(e.tab, r < last ? r : last);
+    }
+  }
+  return v;
+}
+
+constexpr u32 kUnroll4 = 2;
+
+template <u32 BASE, u32 PS>
+__device__ __forceinline__ void mat_int4(const Ctx& c, const IntEval& e, u32* __restrict__ dst, u32 count) {
+  const u32 tid = threadIdx.x;
+  const u32 quads = count & ~3u;
+  const __amdgpu_buffer_rsrc_t seq_rsrc =
+      BASE == B_SEQ ? (e.tab.loc == LOC_LDS ? make_rsrc(nullptr, 0) : make_rsrc(e.tab.g, e.tab.count * 4))
+                    : make_rsrc(nullptr, 0);
+  u32 bad = 0;
+  for (u32 base = 0; base < quads; base += kBlockThreads * 4 * kUnroll4) {
+    u32x4 v[kUnroll4];
+#pragma unroll
+    for (u32 u = 0; u < kUnroll4; u++) {
+      const u32 i = base + (u * kBlockThreads + tid) * 4;
+      v[u] = eval_int4_base<BASE>(e, i < quads ? i : quads - 4, seq_rsrc);
+    }
+#pragma unroll
+    for (u32 u = 0; u < kUnroll4; u++) {
+      v[u].x = apply_posts<PS>(e, v[u].x, bad);
+      v[u].y = apply_posts<PS>(e, v[u].y, bad);
+      v[u].z = apply_posts<PS>(e, v[u].z, bad);
+      v[u].w = apply_posts<PS>(e, v[u].w, bad);
+    }
+#pragma unroll
+    for (u32 u = 0; u < kUnroll4; u++) {
+      const u32 i = base + (u * kBlockThreads + tid) * 4;
+      if (i < quads) *reinterpret_cast<u32x4*>(dst + i) = v[u];
+    }
+  }
+  if (tid < count - quads) dst[quads + tid] = eval_int<BASE, false, PS>(e, quads + tid, bad);
+  report(c, bad);
+}
+
+// Whether a root pipe can take the four-rows-per-lane path into a 16-byte aligned output.
+__device__ __forceinline__ bool wide_rows(const IntEval& e, const Tab& out, u32 count) {
+  if (out.loc == LOC_LDS || (reinterpret_cast<u64>(out.g) & 15) != 0 || count < 4) return false;
+  if (e.base == B_SEQ) return e.tab.loc != LOC_LDS && e.tab.esize == 4;
+  if (e.base == B_RLE || e.base == B_FREQ) return e.tab.count > 0 || e.base == B_FREQ;
+  return e.base == B_ONE;
+}
+
+template <u32 BASE>
+__device__ __forceinline__ void mat_int4_ps(const Ctx& c, const IntEval& e, const Tab& out, u32 count) {
+  u32* dst = reinterpret_cast<u32*>(const_cast<u8*>(out.g));
+  switch (post_signature(e)) {
+    case PS_NONE: mat_int4<BASE, PS_NONE>(c, e, dst, count); break;
+    case PS_ADD: mat_int4<BASE, PS_ADD>(c, e, dst, count); break;
+    case PS_DICT_LDS: mat_int4<BASE, PS_DICT_LDS>(c, e, dst, count); break;
+    default: mat_int4<BASE, PS_GEN>(c, e, dst, count); break;
+  }
 }
 
 // Widths and first words of the four miniblocks of a group, per lane: lanes 0-31 work on
@@ -833,60 +948,100 @@ __device__ __forceinline__ void barrier_lds() {  // LDS accesses of this wave co
   asm volatile("" ::: "memory");
 }
 
-__device__ __forceinline__ u32 ring_word(u32 ring_off, u32 w) {
-  return lds32(ring_off + ((w & (kRingWords - 1)) << 2));
+// The ring starts at LDS offset 0; the word behind it mirrors ring word 0, so that the two
+// consecutive words an extraction needs can always be read at a and a + 4.
+__device__ __forceinline__ u32 ring_word(u32 w) { return lds32((w << 2) & (kStreamRingBytes - 1)); }
+
+// Lane-constant selectors of the unpackers: lane l produces values l and l + 64 of a group, i.e.
+// position l % 32 of miniblocks l / 32 and l / 32 + 2.
+struct UnpackLane {
+  u32 k;             // position inside the miniblock
+  u32 sh_lo, sh_hi;  // bit position of the miniblock's width byte in the group header
+  u32 pm_lo, pm_hi;  // header bytes of the miniblocks in front of it
+  u32 row4;          // byte offset of the lane's first row inside the group's 512 output bytes
+};
+__device__ __forceinline__ UnpackLane unpack_lane() {
+  const u32 lane = threadIdx.x & 63, h = lane >> 5;
+  UnpackLane u;
+  u.k = lane & 31;
+  u.sh_lo = 24 - 8 * h;
+  u.sh_hi = 8 - 8 * h;
+  u.pm_lo = h ? 0xFF000000u : 0u;
+  u.pm_hi = h ? 0xFFFFFF00u : 0xFFFF0000u;
+  u.row4 = lane * 4;
+  return u;
 }
 
-__device__ __forceinline__ u32 ring_extract(u32 ring_off, u32 base_word, u32 b, u32 k) {
-  const u32 bit = k * b;
-  const u32 w = base_word + (bit >> 5);
-  const u32 lo = ring_word(ring_off, w), hi = ring_word(ring_off, w + 1);
-  const u32 v = __builtin_amdgcn_alignbit(hi, lo, bit);
-  return b >= 32 ? v : (v & ((1u << b) - 1u));
+// One value out of the ring. `first` is the first payload word of the group, `hdr` its header
+// (b0<<24)|(b1<<16)|(b2<<8)|b3; the miniblock is picked by (sh, pm). Value k of a miniblock of
+// width b occupies bits [k*b, (k+1)*b) of the miniblock's little-endian bit stream. A width above
+// 32 (flagged by the walker) yields garbage but stays inside the ring.
+__device__ __forceinline__ u32 ring_extract(u32 first, u32 hdr, u32 sh, u32 pm, u32 k) {
+  const u32 b = __builtin_amdgcn_ubfe(hdr, sh, 8);
+  const u32 w = __builtin_amdgcn_sad_u8(hdr & pm, 0u, first);
+  const u32 bit = __umul24(k, b);
+  const u32 a = ((w + (bit >> 5)) << 2) & (kStreamRingBytes - 1);
+  const u32 lo = lds32(a), hi = lds32(a + 4);
+  const u32 x = __builtin_amdgcn_alignbit(hi, lo, bit);
+  const u32 full = (u32)__builtin_amdgcn_sbfe(b, 5, 1);  // all ones when b == 32
+  return __builtin_amdgcn_ubfe(x, 0u, b) | (x & full);
 }
 
-constexpr u32 kRingGroupsPerIter = 4;
-
-// Groups [g_lo, g_hi) unpacked from the ring by unpack wave `uw`; lane l produces values l and
-// l+64 of a group.
+// Post-op of a streamed root, resolved once per workgroup.
+struct StreamPost {
+  u32 bias;                       // PS_ADD
+  u32 n, dict_off;                // PS_DICT_*: dictionary size; LDS offset of its copy
+  __amdgpu_buffer_rsrc_t dict_g;  // PS_DICT_GLB: the dictionary inside the compressed bytes
+};
+// Dictionary codes are not clamped per value: the largest one is tracked in `code_max` and
+// checked once; an LDS read is clamped by one min, a buffer load past the end returns 0.
 template <u32 PS>
-__device__ __forceinline__ void ring_eval_groups(const IntEval& e, u32* __restrict__ dst, u32 ring_off, u32 g_lo,
-                                                 u32 g_hi, u32 uw, u32& bad) {
-  const u32 lane = threadIdx.x & 63;
-  const BpView& bp = e.bp;
-  const u32 k = lane & 31;
-  const u32 upper_mask = lane >= 32 ? ~0u : 0u;
-  for (u32 g0 = g_lo + uw * kRingGroupsPerIter; g0 < g_hi; g0 += kUnpackWaves * kRingGroupsPerIter) {
-    u32 v[kRingGroupsPerIter][2];
+__device__ __forceinline__ u32 stream_post(const StreamPost& sp, u32 v, u32& code_max) {
+  if (PS == PS_ADD) return v + sp.bias;
+  if (PS == PS_DICT_LDS) {
+    code_max = code_max > v ? code_max : v;
+    v = v < sp.n ? v : sp.n - 1;
+    return lds32(sp.dict_off + 4 * v);
+  }
+  if (PS == PS_DICT_GLB) {
+    code_max = code_max > v ? code_max : v;
+    return __builtin_amdgcn_raw_buffer_load_b32(sp.dict_g, v << 2, 0, 0);
+  }
+  return v;
+}
+
+// Groups g_lo + uw, + kUnpackWaves, ... below g_hi, two per iteration. Rows go out through a
+// buffer resource that ends at the last packed row, so a partial last group needs no masking.
+template <u32 PS>
+__device__ __forceinline__ void ring_eval_groups(const StreamPost& sp, const UnpackLane& u,
+                                                 __amdgpu_buffer_rsrc_t dst_rsrc, u32 index_off, u32 g_lo, u32 g_hi,
+                                                 u32 uw, u32& code_max) {
+  for (u32 g = g_lo + uw; g < g_hi; g += 2 * kUnpackWaves) {
+    const u32 g2 = g + kUnpackWaves;
+    const bool two = g2 < g_hi;
+    const u64 e1 = lds64(index_off + 8 * g), e2 = lds64(index_off + 8 * (two ? g2 : g));
+    u32 v[4];
+    v[0] = ring_extract((u32)e1, (u32)(e1 >> 32), u.sh_lo, u.pm_lo, u.k);
+    v[1] = ring_extract((u32)e1, (u32)(e1 >> 32), u.sh_hi, u.pm_hi, u.k);
+    v[2] = ring_extract((u32)e2, (u32)(e2 >> 32), u.sh_lo, u.pm_lo, u.k);
+    v[3] = ring_extract((u32)e2, (u32)(e2 >> 32), u.sh_hi, u.pm_hi, u.k);
 #pragma unroll
-    for (u32 j = 0; j < kRingGroupsPerIter; j++) {
-      const u32 g = g0 + j < g_hi ? g0 + j : g_hi - 1;
-      const LaneGroup lg = lane_group(lds64(bp.index_off + 8 * g), upper_mask);
-      v[j][0] = ring_extract(ring_off, lg.w_lo, lg.b_lo, k);
-      v[j][1] = ring_extract(ring_off, lg.w_hi, lg.b_hi, k);
-    }
-#pragma unroll
-    for (u32 j = 0; j < kRingGroupsPerIter; j++) {
-      v[j][0] = apply_posts<PS>(e, v[j][0], bad);
-      v[j][1] = apply_posts<PS>(e, v[j][1], bad);
-    }
-#pragma unroll
-    for (u32 j = 0; j < kRingGroupsPerIter; j++) {
-      const u32 i = (g0 + j) * btrfmt::FBP_GROUP + lane;
-      if (g0 + j < g_hi) {
-        if (i < bp.rounded) dst[i] = v[j][0];
-        if (i + 64 < bp.rounded) dst[i + 64] = v[j][1];
-      }
-    }
+    for (u32 j = 0; j < 4; j++) v[j] = stream_post<PS>(sp, v[j], code_max);
+    const u32 o1 = g * (btrfmt::FBP_GROUP * 4) + u.row4;
+    const u32 o2 = (two ? g2 * (btrfmt::FBP_GROUP * 4) : 0x80000000u) + u.row4;  // out of range: dropped
+    __builtin_amdgcn_raw_buffer_store_b32(v[0], dst_rsrc, o1, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b32(v[1], dst_rsrc, o1 + 256, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b32(v[2], dst_rsrc, o2, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b32(v[3], dst_rsrc, o2 + 256, 0, 0);
   }
 }
 
-// One batch of the header chain, read from the ring (same stepping as walker_advance).
-__device__ __forceinline__ void ring_walk_batch(u32 ring_off, u32 index_off, u32 t, u32 groups, u32& pos, u32& g,
-                                                u32& bad_hdr) {
+// One batch of the header chain, read from the ring (same stepping as walker_advance). Index
+// entries are {first payload word, header}.
+__device__ __forceinline__ void ring_walk_batch(u32 index_off, u32 t, u32 groups, u32& pos, u32& g, u32& bad_hdr) {
   const u32 lane = threadIdx.x & 63;
   const u32 bb = t * kBatchWords;
-  const u32 slot = ring_off + (t & (kRingBatches - 1)) * (kBatchWords * 4);
+  const u32 slot = (t & (kRingBatches - 1)) * (kBatchWords * 4);
   u32 d[kWalkBatch];
 #pragma unroll
   for (u32 k = 0; k < kWalkBatch; k++)
@@ -902,9 +1057,9 @@ __device__ __forceinline__ void ring_walk_batch(u32 ring_off, u32 index_off, u32
     m = m == 63 && (ok >> 63) ? 64 : m;
     m = m < groups - g ? m : groups - g;
     if (lane < m) {
-      const u32 hv = ring_word(ring_off, bb + pj);
+      const u32 hv = ring_word(bb + pj);
       if ((hv & 0xC0C0C0C0u) || ((hv + 0x5F5F5F5Fu) & 0x80808080u)) bad_hdr = 1;  // widths must be <= 32
-      lds_st64(index_off + 8 * (g + lane), ((u64)hv << 32) | (bb + pj));
+      lds_st64(index_off + 8 * (g + lane), ((u64)hv << 32) | (bb + pj + 1));
     }
     g = uniform(g + m);
     pos = uniform(pos + m * D);
@@ -912,8 +1067,7 @@ __device__ __forceinline__ void ring_walk_batch(u32 ring_off, u32 index_off, u32
 }
 
 template <u32 PS>
-__device__ __forceinline__ void stream_int_bp(const Ctx& c, const Pipe& p, const IntEval& e, u32* __restrict__ dst,
-                                              u32 ring_off) {
+__device__ __forceinline__ void stream_int_bp(const Ctx& c, const Pipe& p, const IntEval& e, u32* __restrict__ dst) {
   const u32 lane = threadIdx.x & 63, wave = uniform(threadIdx.x >> 6);
   const u32 W = uniform(p.a[1]), groups = uniform(p.a[5]);
   const u32 index_off = e.bp.index_off;
@@ -925,12 +1079,17 @@ __device__ __forceinline__ void stream_int_bp(const Ctx& c, const Pipe& p, const
     const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(e.bp.base, e.bp.bytes);
     auto issue = [&](u32 t) {
       if (t >= batches) return;
-      const u32 slot = ring_off + (t & (kRingBatches - 1)) * (kBatchWords * 4);
+      const u32 slot = (t & (kRingBatches - 1)) * (kBatchWords * 4);
 #pragma unroll
       for (u32 k = 0; k < kWalkBatch; k++)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(
             rsrc, (__attribute__((address_space(3))) void*)(lds_raw + slot + k * 1024), 16,
             (t * kBatchWords + 256 * k + 4 * lane) * 4, 0, 0, 0);
+    };
+    // the word behind the ring follows ring word 0 (rewritten whenever a batch lands in slot 0)
+    auto mirror = [&]() {
+      if (lane == 0) lds_st32(kStreamRingBytes, lds32(0));
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     };
     for (u32 t = 0; t < kRingAhead; t++) issue(t);
     // batches 0 and 1 landed (only batch 2 may still be in flight), then the start barrier
@@ -938,6 +1097,7 @@ __device__ __forceinline__ void stream_int_bp(const Ctx& c, const Pipe& p, const
       asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    mirror();
     __builtin_amdgcn_s_barrier();
     for (u32 t = 0; t < batches; t++) {
       // before barrier t: batch t+1 landed; at most batch t+2 stays in flight
@@ -945,36 +1105,45 @@ __device__ __forceinline__ void stream_int_bp(const Ctx& c, const Pipe& p, const
         asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
       else
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (((t + 1) & (kRingBatches - 1)) == 0) mirror();
       __builtin_amdgcn_s_barrier();
       issue(t + kRingAhead);  // its slot held batch t-1, fully consumed before this barrier
     }
   } else if (wave == 0) {
     // ---- walker: batch 0 before barrier 0, then batch t+1 during iteration t
     u32 pos = 1, g = 0, bad_hdr = 0;
+    const u32 tail_word = load_tail_words(make_rsrc(e.bp.base, e.bp.bytes), W);
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    ring_walk_batch(ring_off, index_off, 0, groups, pos, g, bad_hdr);
+    ring_walk_batch(index_off, 0, groups, pos, g, bad_hdr);
     if (lane == 0) lds_st32(found_off, g);
     for (u32 t = 0; t < batches; t++) {
       barrier_lds();
       if (t + 1 < batches) {
-        ring_walk_batch(ring_off, index_off, t + 1, groups, pos, g, bad_hdr);
+        ring_walk_batch(index_off, t + 1, groups, pos, g, bad_hdr);
         if (lane == 0) lds_st32(found_off + 4 * ((t + 1) & 1), g);
       }
     }
-    // sentinel, flags and the VariableByte tail (read from global memory)
-    walker_finish(WalkEnd{e.bp.base, W, e.bp.rounded, groups, index_off, pos, g, __any(bad_hdr) ? 1u : 0u}, c, p);
+    // sentinel, flags and the VariableByte tail
+    walker_finish(WalkEnd{W, e.bp.rounded, groups, index_off, pos, g, __any(bad_hdr) ? 1u : 0u, tail_word}, c, p);
   } else {
     // ---- unpackers: the groups that start in batch t, during iteration t
-    u32 g_lo = 0, bad = 0;
+    const UnpackLane u = unpack_lane();
+    const __amdgpu_buffer_rsrc_t dst_rsrc = make_rsrc(dst, e.bp.rounded * 4);
+    StreamPost sp;
+    sp.bias = e.post_bias[0];
+    sp.n = e.post_tab[0].count;
+    sp.dict_off = e.post_tab[0].lds;
+    sp.dict_g = make_rsrc(PS == PS_DICT_GLB ? e.post_tab[0].g : e.bp.base, PS == PS_DICT_GLB ? sp.n * 4 : 0);
+    u32 g_lo = 0, code_max = 0;
     __builtin_amdgcn_s_barrier();
     for (u32 t = 0; t < batches; t++) {
       barrier_lds();
       const u32 g_hi = uniform(lds32(found_off + 4 * (t & 1)));
-      ring_eval_groups<PS>(e, dst, ring_off, g_lo, g_hi, wave - 1, bad);
+      ring_eval_groups<PS>(sp, u, dst_rsrc, index_off, g_lo, g_hi, wave - 1, code_max);
       g_lo = g_hi;
     }
-    report(c, bad);
+    if ((PS == PS_DICT_LDS || PS == PS_DICT_GLB) && code_max >= sp.n) raise(c, ST_DICT_CODE);
   }
   __syncthreads();
   {
@@ -1023,6 +1192,15 @@ __device__ __forceinline__ void materialize(const Ctx& c, u32 pipe_id, u32 seq_i
   if (count == 0) return;
   if (!is_double) {
     const IntEval e = resolve_int(c, pipe_id);
+    if (wide_rows(e, out, count)) {
+      switch (e.base) {
+        case B_SEQ: mat_int4_ps<B_SEQ>(c, e, out, count); break;
+        case B_ONE: mat_int4_ps<B_ONE>(c, e, out, count); break;
+        case B_RLE: mat_int4_ps<B_RLE>(c, e, out, count); break;
+        default: mat_int4_ps<B_FREQ>(c, e, out, count); break;
+      }
+      return;
+    }
     switch (e.base) {
       case B_SEQ: mat_int_ps<B_SEQ>(c, e, out, count); break;
       case B_ONE: mat_int<B_ONE, PS_GEN>(c, e, out, count); break;
@@ -1065,18 +1243,18 @@ __device__ __forceinline__ void materialize(const Ctx& c, u32 pipe_id, u32 seq_i
 }
 
 // ---- bitmap steps ----------------------------------------------------------------------------------
-__device__ inline void bitmap_or(u32 bits_off, u32 row) {
+__device__ __forceinline__ void bitmap_or(u32 bits_off, u32 row) {
   atomicOr(reinterpret_cast<u32*>(lds_raw + bits_off + 4 * (row >> 5)), 1u << (row & 31));
 }
 
-__device__ void bitmap_clear(const Ctx& c, const Step& s) {
+__device__ __forceinline__ void bitmap_clear(const Ctx& c, const Step& s) {
   const Seq& bm = seq_at(c, uniform(s.a[1]));
   const u32 off = c.table_base + uniform(bm.off), words = uniform(bm.count) * 2;
   for (u32 w = threadIdx.x; w < words; w += kBlockThreads) lds_st32(off + 4 * w, 0);
 }
 
 // Members of one CRoaring container (or of the whole bitmap for the u32-array form) -> bits.
-__device__ void bitmap_set(const Ctx& c, const Step& s) {
+__device__ __forceinline__ void bitmap_set(const Ctx& c, const Step& s) {
   const u8* src = c.src + uniform(s.a[0]);
   const u32 bits_off = seq_lds(c, uniform(s.a[1]));
   const u32 count = uniform(s.a[2]), first = uniform(s.a[3]), nbits = uniform(s.a[4]), kind = uniform(s.a[5]);
@@ -1133,32 +1311,37 @@ __device__ void bitmap_set(const Ctx& c, const Step& s) {
 }
 
 // Run lengths -> run starts (exclusive scan) -> one start flag per run (templated/RLE.hpp:164-191
-// expands runs back to back; the start of run r is the sum of the lengths before it).
-__device__ void bitmap_starts(const Ctx& c, const Step& s) {
+// expands runs back to back; the start of run r is the sum of the lengths before it). Every
+// thread owns a contiguous slice of runs, so one block-wide scan covers any run count.
+__device__ __forceinline__ void bitmap_starts(const Ctx& c, const Step& s) {
   const Tab len = resolve_tab(c, uniform(s.a[0]));
   const u32 bits_off = seq_lds(c, uniform(s.a[1]));
   const u32 nbits = uniform(s.a[3]), runs = uniform(s.a[4]);
-  u32 carry = 0, bad = 0;
-  for (u32 base = 0; base < runs; base += kBlockThreads) {
-    const u32 r = base + threadIdx.x;
-    const int l = r < runs ? (int)tab_ld32(len, r) : 0;
-    if (r < runs && l <= 0) bad = 1;
-    u32 total;
-    const u32 start = carry + block_exclusive_scan(c, l > 0 ? (u32)l : 0u, &total);
-    if (r < runs) {
-      if (start < nbits)
-        bitmap_or(bits_off, start);
-      else
-        bad = 1;
-    }
-    carry += total;
+  const u32 per = (runs + kBlockThreads - 1) / kBlockThreads;
+  const u32 r_lo = threadIdx.x * per < runs ? threadIdx.x * per : runs;
+  const u32 r_hi = r_lo + per < runs ? r_lo + per : runs;
+  u32 sum = 0, bad = 0;
+  for (u32 r = r_lo; r < r_hi; r++) {
+    const int l = (int)tab_ld32(len, r);
+    bad |= l <= 0;
+    sum += l > 0 ? (u32)l : 0u;
   }
-  if (carry != nbits && threadIdx.x == 0) bad = 1;
+  u32 total;
+  u32 start = block_exclusive_scan(c, sum, &total);
+  for (u32 r = r_lo; r < r_hi; r++) {
+    const int l = (int)tab_ld32(len, r);
+    if (start < nbits)
+      bitmap_or(bits_off, start);
+    else
+      bad = 1;
+    start += l > 0 ? (u32)l : 0u;
+  }
+  if (total != nbits && threadIdx.x == 0) bad = 1;
   if (bad) raise(c, ST_RLE_COUNTS);
 }
 
 // bit i = (pipe[i] == value); each wave writes the 64-bit ballot of its 64 consecutive rows.
-__device__ void bitmap_eq(const Ctx& c, const Step& s) {
+__device__ __forceinline__ void bitmap_eq(const Ctx& c, const Step& s) {
   const IntEval e = resolve_int(c, uniform(s.a[0]));
   const u32 bits_off = seq_lds(c, uniform(s.a[1]));
   const u32 nbits = uniform(s.a[3]), value = uniform(s.a[4]);
@@ -1174,25 +1357,28 @@ __device__ void bitmap_eq(const Ctx& c, const Step& s) {
   report(c, bad);
 }
 
-__device__ void bitmap_rank(const Ctx& c, const Step& s) {
+// rank[w] = set bits in words [0, w): every thread owns a contiguous slice of words.
+__device__ __forceinline__ void bitmap_rank(const Ctx& c, const Step& s) {
   const Seq& bm = seq_at(c, uniform(s.a[1]));
   const u32 bits_off = c.table_base + uniform(bm.off), words = uniform(bm.count);
   const u32 rank_off = seq_lds(c, uniform(s.a[2]));
-  u32 carry = 0;
-  for (u32 base = 0; base < words; base += kBlockThreads) {
-    const u32 w = base + threadIdx.x;
-    const u32 pc = w < words ? __popcll(lds64(bits_off + 8 * w)) : 0;
-    u32 total;
-    const u32 ex = carry + block_exclusive_scan(c, pc, &total);
-    if (w < words) lds_st32(rank_off + 4 * w, ex);
-    carry += total;
+  const u32 per = (words + kBlockThreads - 1) / kBlockThreads;
+  const u32 w_lo = threadIdx.x * per < words ? threadIdx.x * per : words;
+  const u32 w_hi = w_lo + per < words ? w_lo + per : words;
+  u32 sum = 0;
+  for (u32 w = w_lo; w < w_hi; w++) sum += __popcll(lds64(bits_off + 8 * w));
+  u32 total;
+  u32 before = block_exclusive_scan(c, sum, &total);
+  for (u32 w = w_lo; w < w_hi; w++) {
+    lds_st32(rank_off + 4 * w, before);
+    before += __popcll(lds64(bits_off + 8 * w));
   }
   const u32 expect = uniform(s.a[4]);
-  if (expect != NONE && carry != expect && threadIdx.x == 0) raise(c, uniform(s.a[5]));
+  if (expect != NONE && total != expect && threadIdx.x == 0) raise(c, uniform(s.a[5]));
 }
 
 // extern/RoaringBitmap.cpp:32-53: one byte per row, 1 = valid.
-__device__ void write_nullmap(const Ctx& c, const Step& s) {
+__device__ __forceinline__ void write_nullmap(const Ctx& c, const Step& s) {
   const u32 type = uniform(s.a[0]), n = uniform(s.a[3]);
   const u32 bits_off = uniform(s.a[1]) == NONE ? 0 : seq_lds(c, uniform(s.a[1]));
   for (u32 i = threadIdx.x; i < n; i += kBlockThreads) {
@@ -1209,18 +1395,18 @@ __device__ void write_nullmap(const Ctx& c, const Step& s) {
   }
 }
 
-// Copies the work item's program into LDS and sets up the workgroup context.
-template <u32 THREADS>
+// Copies the work item's program into LDS at byte offset BASE and sets up the workgroup context.
+template <u32 THREADS, u32 BASE>
 __device__ __forceinline__ ProgramHeader load_program(const WorkItem& it, u32 item, const u8* __restrict__ programs,
                                                       u32* __restrict__ status, Ctx& c) {
   const u32 tid = threadIdx.x;
   {
     const u32* prog = reinterpret_cast<const u32*>(programs + it.prog_off);
-    for (u32 o = tid; o < it.prog_bytes / 4; o += THREADS) lds_st32(4 * o, prog[o]);
+    for (u32 o = tid; o < it.prog_bytes / 4; o += THREADS) lds_st32(BASE + 4 * o, prog[o]);
     if (tid == 0) status[item] = 0;  // later raise() calls are ordered behind the barrier
   }
   __syncthreads();
-  ProgramHeader hdr = *reinterpret_cast<const ProgramHeader*>(lds_raw);
+  ProgramHeader hdr = *reinterpret_cast<const ProgramHeader*>(lds_raw + BASE);
   hdr.n_steps = uniform(hdr.n_steps);
   hdr.n_bp_steps = uniform(hdr.n_bp_steps);
   hdr.n_pipes = uniform(hdr.n_pipes);
@@ -1230,7 +1416,7 @@ __device__ __forceinline__ ProgramHeader load_program(const WorkItem& it, u32 it
   c.nullmap = reinterpret_cast<u8*>(it.nullmap_dst);
   c.scratch = reinterpret_cast<u8*>(it.scratch);
   c.status = status + item;
-  c.steps_off = sizeof(ProgramHeader);
+  c.steps_off = BASE + sizeof(ProgramHeader);
   c.pipes_off = c.steps_off + hdr.n_steps * sizeof(Step);
   c.seqs_off = c.pipes_off + hdr.n_pipes * sizeof(Pipe);
   c.table_base = hdr.table_base;
@@ -1247,7 +1433,7 @@ __device__ __forceinline__ void stream_block(const WorkItem* __restrict__ items,
   const u32 item = order[blockIdx.x];
   const WorkItem it = items[item];
   Ctx c;
-  const ProgramHeader hdr = load_program<kStreamThreads>(it, item, programs, status, c);
+  const ProgramHeader hdr = load_program<kStreamThreads, kStreamProgBase>(it, item, programs, status, c);
   for (u32 s = 0; s + 1 < hdr.n_steps; s++) {  // dictionary copies: a bare source sequence -> LDS
     const Step& st = step_at(c, s);
     const Tab from = resolve_tab(c, uniform(pipe_at(c, uniform(st.a[0])).a[0]));
@@ -1258,27 +1444,32 @@ __device__ __forceinline__ void stream_block(const WorkItem* __restrict__ items,
   const Step& root = step_at(c, hdr.n_steps - 1);
   const u32 pipe_id = uniform(root.a[0]);
   const IntEval e = resolve_int(c, pipe_id);
-  stream_int_bp<PS>(c, pipe_at(c, pipe_id), e, reinterpret_cast<u32*>(c.dst), seq_lds(c, uniform(root.a[2])));
+  stream_int_bp<PS>(c, pipe_at(c, pipe_id), e, reinterpret_cast<u32*>(c.dst));
 }
 
 template <bool DOUBLE_KERNEL>
-__device__ inline void decode_block(const WorkItem* __restrict__ items, const u32* __restrict__ order,
+__device__ __forceinline__ void decode_block(const WorkItem* __restrict__ items, const u32* __restrict__ order,
                                     const u8* __restrict__ programs, u32* __restrict__ status) {
   const u32 item = order[blockIdx.x];
   const WorkItem it = items[item];
   const u32 tid = threadIdx.x;
   Ctx c;
-  const ProgramHeader hdr = load_program<kBlockThreads>(it, item, programs, status, c);
+  stamp(it, 0);
+  const ProgramHeader hdr = load_program<kBlockThreads, 0>(it, item, programs, status, c);
+  stamp(it, 1);
 
   // bit-unpack indexes: one stream per wave, streams in parallel
-  if (!(it.debug_flags & 1))
+  if (!(it.debug_flags & 5))
     for (u32 s = uniform(tid >> 6); s < hdr.n_bp_steps; s += kBlockThreads / 64)
       bp_index_wave(c, pipe_at(c, uniform(step_at(c, s).a[0])));
   __syncthreads();
+  stamp(it, 2);
 
   for (u32 s = hdr.n_bp_steps; s < hdr.n_steps; s++) {
     const Step& st = step_at(c, s);
     if ((it.debug_flags & 2) && s + 1 == hdr.n_steps) break;
+    if ((it.debug_flags & 4) && s + 1 != hdr.n_steps) continue;  // root step only, over whatever LDS holds
+    if ((it.debug_flags >> 8) && s - hdr.n_bp_steps + 1 >= (it.debug_flags >> 8)) break;  // stop after k-1 steps
     switch (uniform(st.kind)) {
       case S_MATERIALIZE: materialize<DOUBLE_KERNEL>(c, uniform(st.a[0]), uniform(st.a[1])); break;
       case S_BITMAP_CLEAR: bitmap_clear(c, st); break;
@@ -1290,6 +1481,7 @@ __device__ inline void decode_block(const WorkItem* __restrict__ items, const u3
       default: break;
     }
     __syncthreads();
+    stamp(it, 3 + s - hdr.n_bp_steps);
   }
 }
 

@@ -83,8 +83,8 @@ enum : uint8_t {
   S_BITMAP_RANK = 6,    // a1 seq bitmap, a2 seq rank, a3 bit count, a4 expected popcount (or NONE),
                         // a5 status bit to raise on a mismatch
   S_NULLMAP = 7,        // a0 nullmap type, a1 seq bitmap (REGULAR/FLIPPED, else NONE), a3 row count
-  S_STREAM_ROOT = 8,    // a0 pipe id (B_BP base), a1 dst seq id, a2 seq id of the LDS ring: root step that
-                        // stages the payload through LDS, indexing and unpacking it batch by batch
+  S_STREAM_ROOT = 8,    // a0 pipe id (B_BP base), a1 dst seq id: root step that stages the payload through
+                        // an LDS ring at the start of LDS, indexing and unpacking it batch by batch
 };
 // Element kinds of S_BITMAP_SET: the four member encodings of CRoaring's native serialization.
 enum : uint32_t { SET_ARRAY32 = 0, SET_ARRAY16 = 1, SET_BITSET = 2, SET_RUNS = 3 };
@@ -99,8 +99,8 @@ struct ProgramHeader {
   uint32_t n_bp_steps;  // the leading S_BP_INDEX steps, run one per wave
   uint32_t n_pipes;
   uint32_t n_seqs;
-  uint32_t table_base;  // LDS byte offset where table space starts (after the program copy and
-                        // 64 bytes of reduction scratch)
+  uint32_t table_base;  // absolute LDS byte offset where table space starts (after the program copy
+                        // and 64 bytes of reduction scratch)
   uint32_t pad[3];
 };
 // A program is laid out as: ProgramHeader | Step[n_steps] | Pipe[n_pipes] | Seq[n_seqs]
@@ -114,9 +114,12 @@ struct WorkItem {
   uint32_t prog_bytes;
   uint32_t tuple_count;
   uint32_t src_bytes;
-  uint32_t debug_flags;  // diagnostics only (BTR_DEBUG_FLAGS): 1 = skip index walks, 2 = skip the root step
+  uint32_t debug_flags;  // diagnostics only (BTR_DEBUG_FLAGS): 1 = skip index walks, 2 = skip the root step,
+                         // 4 = root step only, 8 = record step timestamps, k << 8 = stop before step k
   uint32_t pad;
+  uint64_t debug_buf;    // flag 8: kDebugSlots 100 MHz timestamps of this item
 };
+constexpr uint32_t kDebugSlots = 16;
 
 // Device status bits, one word per work item.
 enum : uint32_t {
@@ -143,6 +146,9 @@ enum : uint32_t {
 
 constexpr uint32_t kBlockThreads = 256;
 constexpr uint32_t kStreamRingBytes = 16 * 1024;  // LDS ring of the streamed root step (4 batches of 1024 words)
+// The stream kernels keep the ring at LDS offset 0 (ring addresses are then a plain mask), one
+// mirror word behind it, and the program copy after that.
+constexpr uint32_t kStreamProgBase = kStreamRingBytes + 16;
 constexpr uint32_t kLdsCapBytes = 160 * 1024;  // all of a gfx950 CU's LDS; typical chunks need 5-40 KiB
 
 }  // namespace btrplan

@@ -475,6 +475,7 @@ void build_program(const ColumnSource& src, BuiltProgram& out) {
     root = bld.dbl_node(src.payload_off, src.scheme, n, 0, desc);
   const uint32_t dst = bld.add_seq(LOC_DST, 0, n, src.column_type == COL_DOUBLE ? 8 : 4);
   uint32_t kernel = src.column_type == COL_DOUBLE ? KERNEL_GENERIC_DBL : KERNEL_GENERIC_INT;
+  uint32_t prog_base = 0;  // LDS byte offset of the program copy
   // A root that reads one full-length bit-packed stream behind at most one post-op (BP, FOR(BP),
   // DICT(BP)) goes to the stream kernels: its only preparation may be dictionary copies into
   // LDS, and its group index is built while decoding instead of in a separate pass.
@@ -487,8 +488,8 @@ void build_program(const ColumnSource& src, BuiltProgram& out) {
                  bld.pipes[st.a[0]].n_post == 0 && bld.seqs[st.a[1]].esize == 4;
     if (eligible) {
       bld.bp_steps.clear();
-      const uint32_t ring = bld.add_seq(LOC_LDS, 0, kStreamRingBytes / 16, 16, true);
-      bld.add_step(S_STREAM_ROOT, root, dst, ring);
+      bld.add_step(S_STREAM_ROOT, root, dst);
+      prog_base = kStreamProgBase;  // the payload ring occupies the start of LDS
       if (rp.n_post == 0)
         kernel = KERNEL_STREAM_NONE;
       else if (rp.post[0].type == POST_ADD)
@@ -516,7 +517,7 @@ void build_program(const ColumnSource& src, BuiltProgram& out) {
   const size_t n_steps = bld.bp_steps.size() + bld.steps.size();
   const size_t prog_bytes = sizeof(ProgramHeader) + n_steps * sizeof(Step) +
                             bld.pipes.size() * sizeof(Pipe) + bld.seqs.size() * sizeof(Seq);
-  const uint32_t table_base = align_up((uint32_t)prog_bytes, 16) + 64;  // + reduction scratch
+  const uint32_t table_base = prog_base + align_up((uint32_t)prog_bytes, 16) + 64;  // + reduction scratch
   uint64_t lds = 0, scratch = 0;
   for (auto& s : bld.seqs)
     if (s.loc == LOC_LDS && s.must_lds) {
