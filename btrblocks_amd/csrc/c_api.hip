@@ -417,7 +417,8 @@ btr_status btr_gpu_ctx_create(int device, btr_gpu_ctx** out) {
   if (!guard.ok) return fail(BTR_ERR_DEVICE, "hipSetDevice failed");
   const void* kernels[] = {(const void*)btr_decode_int_kernel,      (const void*)btr_decode_dbl_kernel,
                            (const void*)btr_stream_none_kernel,     (const void*)btr_stream_add_kernel,
-                           (const void*)btr_stream_dict_lds_kernel, (const void*)btr_stream_dict_glb_kernel};
+                           (const void*)btr_stream_dict_lds_kernel, (const void*)btr_stream_dict_glb_kernel,
+                           (const void*)btr_stream_pseudo_kernel};
   for (const void* k : kernels) {
     hipFuncAttributes attr;
     e = hipFuncGetAttributes(&attr, k);
@@ -553,7 +554,8 @@ btr_status btr_gpu_decode(btr_gpu_ctx* ctx, btr_gpu_plan* plan, void* hip_stream
   using Kernel = void (*)(const WorkItem*, const uint32_t*, const uint8_t*, uint32_t*);
   static const Kernel kernels[KERNEL_KINDS] = {btr_decode_int_kernel,      btr_decode_dbl_kernel,
                                                btr_stream_none_kernel,     btr_stream_add_kernel,
-                                               btr_stream_dict_lds_kernel, btr_stream_dict_glb_kernel};
+                                               btr_stream_dict_lds_kernel, btr_stream_dict_glb_kernel,
+                                               btr_stream_pseudo_kernel};
   for (uint32_t kind = 0; kind < KERNEL_KINDS; kind++) {
     const size_t n = plan->kind_begin[kind + 1] - plan->kind_begin[kind];
     if (n == 0) continue;

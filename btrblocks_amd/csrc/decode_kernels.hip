@@ -192,6 +192,9 @@ __device__ __forceinline__ void tab_st64(const Tab& t, u32 i, u64 v) {
 }
 
 // ---- bitmap + rank ---------------------------------------------------------------------------
+__device__ __forceinline__ void bitmap_or(u32 bits_off, u32 row) {
+  atomicOr(reinterpret_cast<u32*>(lds_raw + bits_off + 4 * (row >> 5)), 1u << (row & 31));
+}
 // bits: u64 words in LDS; rank[w] = set bits in words [0, w).
 struct RankView {
   u32 bits_off, rank_off;
@@ -529,6 +532,7 @@ __device__ __forceinline__ u64 eval_dbl(const DblEval& e, u32 i, u32& bad) {
 }
 
 // ---- block-wide exclusive scan of one value per thread ------------------------------------------
+template <u32 THREADS = kBlockThreads>
 __device__ __forceinline__ u32 block_exclusive_scan(const Ctx& c, u32 v, u32* total) {
   const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   u32 incl = v;
@@ -542,7 +546,7 @@ __device__ __forceinline__ u32 block_exclusive_scan(const Ctx& c, u32 v, u32* to
   __syncthreads();
   u32 before = 0, sum = 0;
 #pragma unroll
-  for (u32 w = 0; w < kBlockThreads / 64; w++) {
+  for (u32 w = 0; w < THREADS / 64; w++) {
     const u32 s = lds32(c.red_off + 4 * w);
     before += w < wave ? s : 0;
     sum += s;
@@ -566,6 +570,7 @@ __device__ __forceinline__ u32 group_lengths(const u32x4& w) {
 }
 
 constexpr u32 kWalkBatch = 4;  // 256-word windows per batch (1024 words, 16 per lane)
+constexpr u32 kBatchWords = 256 * kWalkBatch;
 
 // "Group length if the word at batch position p were a header", gathered from the lane that
 // holds it: lane (p/4)%64 keeps byte p%4 of window p/256.
@@ -580,17 +585,132 @@ __device__ __forceinline__ u32 length_at(const u32 (&d)[kWalkBatch], u32 p) {
   return (v >> (8 * (p & 3))) & 0xFF;
 }
 
+// The same for a wave-uniform position: scalar lane reads, no cross-lane traffic.
+__device__ __forceinline__ u32 length_at_uniform(const u32 (&d)[kWalkBatch], u32 p) {
+  const u32 sl = (p >> 2) & 63;
+  u32 v = __builtin_amdgcn_readlane(d[0], sl);
+#pragma unroll
+  for (u32 k = 1; k < kWalkBatch; k++) {
+    const u32 t = __builtin_amdgcn_readlane(d[k], sl);
+    v = (p >> 8) == k ? t : v;
+  }
+  return (v >> (8 * (p & 3))) & 0xFF;
+}
+
+// Follows the header chain "next header = this header + 1 + sum of its four width bytes" through
+// one batch whose per-word lengths sit in d[]. Two kinds of step:
+//   run      the length D at `pos` is read and lane j checks the word at pos + j*D: the leading run
+//            of lanes that also find length D are real headers (lane 0 is one by construction, and
+//            a confirmed lane j makes the guess of lane j+1 exact), so a stretch of equally wide
+//            groups costs one step for up to 64 groups;
+//   jumps    when widths change from group to group the chain is resolved by pointer doubling in
+//            an LDS table: J_0[p] = p + length(p) for all 1024 positions of the batch, J_{r+1} =
+//            J_r o J_r; the set of reached positions doubles per round (lane j ends up with the
+//            j-th group), so a batch costs O(log groups) wave-wide rounds instead of one serial
+//            step per group.
+// The jump tables need kWalkScratchBytes of LDS (`jump_off`, or NONE: run steps only - enough for
+// short streams). emit(first_group, count, position) is called with a per-lane position for
+// lanes < count.
+constexpr u32 kJumpEntries = kBatchWords + 256;  // positions past the batch map to themselves
+static_assert(kWalkScratchBytes == kJumpEntries * 2, "one u16 table; the size is shared with the plan compiler");
+
+struct ChainState {
+  u32 pos, g;   // next header position, groups found
+  u32 spec_ok;  // the last batch was made of equally long groups: try a run step first
+};
+
+__device__ __forceinline__ u32 lds16(u32 off) { return *reinterpret_cast<const u16*>(lds_raw + off); }
+
+// Entries [kBatchWords, kJumpEntries) of the table: self loops. Once per walker scratch.
+__device__ __forceinline__ void jump_tables_init(u32 jump_off) {
+  if (jump_off == NONE) return;
+  const u32 lane = threadIdx.x & 63;
+  const u32 p = kBatchWords + 4 * lane;
+  lds_st64(jump_off + 2 * p, (u64)(p | ((p + 1) << 16)) | ((u64)((p + 2) | ((p + 3) << 16)) << 32));
+}
+
+template <typename Emit>
+__device__ __forceinline__ void walk_chain(const u32 (&d)[kWalkBatch], u32 bb, u32 groups, u32 jump_off, ChainState& st,
+                                           Emit emit) {
+  const u32 lane = threadIdx.x & 63;
+  while (st.pos < bb + kBatchWords && st.g < groups) {
+    const u32 rel = st.pos - bb;
+    if (st.spec_ok || jump_off == NONE) {
+      const u32 D = length_at_uniform(d, rel);
+      const u32 pj = rel + lane * D;
+      const bool inside = pj < kBatchWords;
+      const u32 dj = length_at(d, inside ? pj : rel);
+      const u64 ok = __ballot(inside && dj == D);
+      u32 m = (u32)__builtin_ctzll(~ok | (1ull << 63));
+      m = m == 63 && (ok >> 63) ? 64 : m;
+      m = m < groups - st.g ? m : groups - st.g;
+      emit(st.g, m, bb + pj);
+      st.g = uniform(st.g + m);
+      st.pos = uniform(st.pos + m * D);
+      if (m < 64 && st.pos < bb + kBatchWords) st.spec_ok = 0;  // the run broke inside the batch
+      continue;
+    }
+    // ---- pointer doubling from `rel`
+#pragma unroll
+    for (u32 k = 0; k < kWalkBatch; k++) {  // J_0 of this lane's own positions 256k + 4*lane + i
+      const u32 p = 256 * k + 4 * lane;
+      const u32 j0 = p + (d[k] & 0xFF), j1 = p + 1 + ((d[k] >> 8) & 0xFF), j2 = p + 2 + ((d[k] >> 16) & 0xFF),
+                j3 = p + 3 + (d[k] >> 24);
+      lds_st64(jump_off + 2 * p, (u64)(j0 | (j1 << 16)) | ((u64)(j2 | (j3 << 16)) << 32));
+    }
+    u32 node = rel, cnt = 1;
+    for (;;) {
+      const u32 nxt = lds16(jump_off + 2 * node);
+      const u32 pulled = __builtin_amdgcn_ds_bpermute((lane - cnt) << 2, nxt);
+      node = (lane >= cnt && lane < 2 * cnt) ? pulled : node;
+      cnt *= 2;
+      const u32 far = __builtin_amdgcn_readlane(node, cnt - 1);
+      if (far >= kBatchWords || cnt == 64) break;
+      // J_{r+1} = J_r o J_r in place: the wave reads all of J_r (its LDS reads are served in
+      // program order) before it writes any of J_{r+1}
+      u32 lo[kWalkBatch], hi[kWalkBatch];
+#pragma unroll
+      for (u32 k = 0; k < kWalkBatch; k++) {
+        const u64 own = lds64(jump_off + 2 * (256 * k + 4 * lane));
+        const u32 j0 = lds16(jump_off + 2 * ((u32)own & 0xFFFF)), j1 = lds16(jump_off + 2 * ((u32)own >> 16)),
+                  j2 = lds16(jump_off + 2 * ((u32)(own >> 32) & 0xFFFF)), j3 = lds16(jump_off + 2 * (u32)(own >> 48));
+        lo[k] = j0 | (j1 << 16);
+        hi[k] = j2 | (j3 << 16);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (u32 k = 0; k < kWalkBatch; k++) lds_st64(jump_off + 2 * (256 * k + 4 * lane), (u64)lo[k] | ((u64)hi[k] << 32));
+    }
+    u32 m = (u32)__popcll(__ballot(lane < cnt && node < kBatchWords));
+    m = m < groups - st.g ? m : groups - st.g;
+    emit(st.g, m, bb + node);
+    // equally spaced groups: the next batch may start with a run step again
+    const u32 step0 = __builtin_amdgcn_readlane(node, 1) - rel;
+    const u32 prev = __builtin_amdgcn_ds_bpermute(((lane ? lane : 1) - 1) << 2, node);
+    st.spec_ok = m >= 4 && __ballot(lane >= 1 && lane < m && node - prev != step0) == 0;
+    u32 next;
+    if (m < cnt) {
+      next = __builtin_amdgcn_readlane(node, m);
+    } else {  // all 64 lanes hold groups inside the batch: go on behind the last one
+      const u32 last = __builtin_amdgcn_readlane(node, 63);
+      next = last + length_at_uniform(d, last);
+    }
+    st.g = uniform(st.g + m);
+    st.pos = uniform(bb + next);
+  }
+}
+
 // Walk state, kept in the registers of the walking wave.
 struct Walker {
   const u8* base;
   u32 W, rounded, groups, index_off;
+  u32 jump_off;    // LDS scratch for the jump tables, or NONE
   u32 pos, g, bb;  // next header position, groups found, first word of the current batch
   u32 bad;
   u32 tail_word;          // word max(W, 64) - 64 + lane of the stream: covers any VariableByte tail
   u32 d[kWalkBatch];      // packed group lengths of the current batch
   u32x4 nxt[kWalkBatch];  // next batch, in flight
 };
-constexpr u32 kBatchWords = 256 * kWalkBatch;
 
 __device__ __forceinline__ u32x4 load_window(__amdgpu_buffer_rsrc_t rsrc, u32 first_word, u32 lane) {
   return __builtin_amdgcn_raw_buffer_load_b128(rsrc, (first_word + 4 * lane) * 4, 0, 0);  // past the end: 0
@@ -603,8 +723,9 @@ __device__ __forceinline__ u32 load_tail_words(__amdgpu_buffer_rsrc_t rsrc, u32 
   return __builtin_amdgcn_raw_buffer_load_b32(rsrc, (first + (threadIdx.x & 63)) * 4, 0, 0);
 }
 
-__device__ __forceinline__ void walker_init(Walker& w, const Ctx& c, const Pipe& p) {
+__device__ __forceinline__ void walker_init(Walker& w, const Ctx& c, const Pipe& p, u32 jump_seq) {
   const u32 lane = threadIdx.x & 63;
+  w.jump_off = jump_seq == NONE ? NONE : seq_lds(c, jump_seq);
   w.base = c.src + uniform(p.a[0]);
   w.W = uniform(p.a[1]);
   w.rounded = uniform(p.a[3]);
@@ -628,40 +749,38 @@ __device__ __forceinline__ void walker_init(Walker& w, const Ctx& c, const Pipe&
 __device__ __forceinline__ void walker_run(Walker& w) {
   const u32 lane = threadIdx.x & 63;
   const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(w.base, w.W * 4);
-  while (w.g < w.groups) {
-    if (w.pos >= w.bb + kBatchWords) {  // move to the next batch
-      if (w.bb + kBatchWords >= w.W) break;
-      w.bb += kBatchWords;
+  ChainState st{w.pos, w.g, 1};
+  const u32 index_off = w.index_off;
+  jump_tables_init(w.jump_off);
+  for (;;) {
+    walk_chain(w.d, w.bb, w.groups, w.jump_off, st, [&](u32 first, u32 count, u32 position) {
+      if (lane < count) lds_st32(index_off + 8 * (first + lane), position);
+    });
+    if (st.g >= w.groups || w.bb + kBatchWords >= w.W) break;
+    w.bb += kBatchWords;  // move to the next batch
 #pragma unroll
-      for (u32 k = 0; k < kWalkBatch; k++) w.d[k] = group_lengths(w.nxt[k]);
+    for (u32 k = 0; k < kWalkBatch; k++) w.d[k] = group_lengths(w.nxt[k]);
 #pragma unroll
-      for (u32 k = 0; k < kWalkBatch; k++) w.nxt[k] = load_window(rsrc, w.bb + kBatchWords + 256 * k, lane);
-      continue;
-    }
-    // One step: read the length D of the group at `pos` and guess that the following groups
-    // have the same length: lane j checks the word at pos + j*D. The leading run of lanes that
-    // also find length D are real headers (lane 0 is one by construction, and a confirmed lane j
-    // makes the guess of lane j+1 exact), so a stretch of equally wide groups costs one step; a
-    // width change ends the run and the next step starts from the first unconfirmed position.
-    const u32 rel = w.pos - w.bb;
-    const u32 D = uniform(length_at(w.d, rel));
-    const u32 pj = rel + lane * D;
-    const bool inside = pj < kBatchWords;
-    const u32 dj = length_at(w.d, inside ? pj : rel);
-    const u64 ok = __ballot(inside && dj == D);
-    u32 m = (u32)__builtin_ctzll(~ok | (1ull << 63));
-    m = m == 63 && (ok >> 63) ? 64 : m;
-    m = m < w.groups - w.g ? m : w.groups - w.g;
-    if (lane < m) lds_st32(w.index_off + 8 * (w.g + lane), w.bb + pj);
-    w.g = uniform(w.g + m);
-    w.pos = uniform(w.pos + m * D);
+    for (u32 k = 0; k < kWalkBatch; k++) w.nxt[k] = load_window(rsrc, w.bb + kBatchWords + 256 * k, lane);
   }
-  // fetch and validate the header word of every group (every width byte must be <= 32)
-  for (u32 gg = lane; gg < w.g; gg += 64) {
-    const u32 gp = lds32(w.index_off + 8 * gg);
-    const u32 hv = __builtin_amdgcn_raw_buffer_load_b32(rsrc, gp * 4, 0, 0);
-    if ((hv & 0xC0C0C0C0u) || ((hv + 0x5F5F5F5Fu) & 0x80808080u)) w.bad = 1;
-    lds_st32(w.index_off + 8 * gg + 4, hv);
+  w.pos = st.pos;
+  w.g = st.g;
+  // fetch and validate the header word of every group (every width byte must be <= 32), four
+  // loads in flight per lane
+  for (u32 g0 = 0; g0 < w.g; g0 += 256) {
+    u32 hv[4];
+#pragma unroll
+    for (u32 j = 0; j < 4; j++) {
+      const u32 gg = g0 + 64 * j + lane;
+      const u32 gp = gg < w.g ? lds32(w.index_off + 8 * gg) : 0x3FFFFFFFu;  // past the end: reads 0
+      hv[j] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, gp * 4, 0, 0);
+    }
+#pragma unroll
+    for (u32 j = 0; j < 4; j++) {
+      const u32 gg = g0 + 64 * j + lane;
+      if ((hv[j] & 0xC0C0C0C0u) || ((hv[j] + 0x5F5F5F5Fu) & 0x80808080u)) w.bad = 1;
+      if (gg < w.g) lds_st32(w.index_off + 8 * gg + 4, hv[j]);
+    }
   }
 }
 
@@ -710,10 +829,13 @@ __device__ __forceinline__ void walker_finish(const WalkEnd& w, const Ctx& c, co
   }
 }
 
-__device__ __forceinline__ void bp_index_wave(const Ctx& c, const Pipe& p) {
+__device__ __forceinline__ void bp_index_wave(const Ctx& c, const Step& s) {
+  const Pipe& p = pipe_at(c, uniform(s.a[0]));
   Walker w;
-  walker_init(w, c, p);
+  __builtin_amdgcn_s_setprio(3);  // a serial chain other waves wait for
+  walker_init(w, c, p, uniform(s.a[1]));
   walker_run(w);
+  __builtin_amdgcn_s_setprio(0);
   walker_finish(WalkEnd{w.W, w.rounded, w.groups, w.index_off, w.pos, w.g, w.bad, w.tail_word}, c, p);
 }
 
@@ -795,6 +917,7 @@ __device__ __forceinline__ u32x4 eval_int4_base(const IntEval& e, u32 i, __amdgp
 }
 
 constexpr u32 kUnroll4 = 2;
+constexpr int kStoreNt = 2;  // cache policy bit of buffer stores: non-temporal
 
 template <u32 BASE, u32 PS>
 __device__ __forceinline__ void mat_int4(const Ctx& c, const IntEval& e, u32* __restrict__ dst, u32 count) {
@@ -821,7 +944,9 @@ __device__ __forceinline__ void mat_int4(const Ctx& c, const IntEval& e, u32* __
 #pragma unroll
     for (u32 u = 0; u < kUnroll4; u++) {
       const u32 i = base + (u * kBlockThreads + tid) * 4;
-      if (i < quads) *reinterpret_cast<u32x4*>(dst + i) = v[u];
+      // non-temporal: the decoded column is written once and not read back by this kernel; keeping
+      // it out of the caches also keeps its write-back out of the next launch's time
+      if (i < quads) __builtin_nontemporal_store(v[u], reinterpret_cast<u32x4*>(dst + i));
     }
   }
   if (tid < count - quads) dst[quads + tid] = eval_int<BASE, false, PS>(e, quads + tid, bad);
@@ -948,9 +1073,38 @@ __device__ __forceinline__ void barrier_lds() {  // LDS accesses of this wave co
   asm volatile("" ::: "memory");
 }
 
-// The ring starts at LDS offset 0; the word behind it mirrors ring word 0, so that the two
-// consecutive words an extraction needs can always be read at a and a + 4.
-__device__ __forceinline__ u32 ring_word(u32 w) { return lds32((w << 2) & (kStreamRingBytes - 1)); }
+// A ring starts at an LDS offset that is a multiple of its size (RING); the word behind it mirrors
+// ring word 0, so that the two consecutive words an extraction needs can always be read at a and
+// a + 4.
+template <u32 RING = 0>
+__device__ __forceinline__ u32 ring_word(u32 w) {
+  return lds32(RING | ((w << 2) & (kStreamRingBytes - 1)));
+}
+
+// Batch t of a payload -> its ring slot, by direct-to-LDS loads (1 KiB per wave instruction).
+template <u32 RING>
+__device__ __forceinline__ void ring_issue(__amdgpu_buffer_rsrc_t rsrc, u32 t, u32 batches) {
+  if (t >= batches) return;
+  const u32 lane = threadIdx.x & 63;
+  const u32 slot = RING + (t & (kRingBatches - 1)) * (kBatchWords * 4);
+#pragma unroll
+  for (u32 k = 0; k < kWalkBatch; k++)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(lds_raw + slot + k * 1024),
+                                             16, (t * kBatchWords + 256 * k + 4 * lane) * 4, 0, 0, 0);
+}
+// Refreshes the mirror word; called by the loading wave after a batch has landed in slot 0.
+template <u32 RING>
+__device__ __forceinline__ void ring_mirror() {
+  if ((threadIdx.x & 63) == 0) lds_st32(RING + kStreamRingBytes, lds32(RING));
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+// The loading wave's wait: everything but the youngest `keep_batches` batches has landed.
+__device__ __forceinline__ void ring_wait(bool keep_one_batch) {
+  if (keep_one_batch)
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
 
 // Lane-constant selectors of the unpackers: lane l produces values l and l + 64 of a group, i.e.
 // position l % 32 of miniblocks l / 32 and l / 32 + 2.
@@ -976,11 +1130,12 @@ __device__ __forceinline__ UnpackLane unpack_lane() {
 // (b0<<24)|(b1<<16)|(b2<<8)|b3; the miniblock is picked by (sh, pm). Value k of a miniblock of
 // width b occupies bits [k*b, (k+1)*b) of the miniblock's little-endian bit stream. A width above
 // 32 (flagged by the walker) yields garbage but stays inside the ring.
+template <u32 RING = 0>
 __device__ __forceinline__ u32 ring_extract(u32 first, u32 hdr, u32 sh, u32 pm, u32 k) {
   const u32 b = __builtin_amdgcn_ubfe(hdr, sh, 8);
   const u32 w = __builtin_amdgcn_sad_u8(hdr & pm, 0u, first);
   const u32 bit = __umul24(k, b);
-  const u32 a = ((w + (bit >> 5)) << 2) & (kStreamRingBytes - 1);
+  const u32 a = RING | (((w + (bit >> 5)) << 2) & (kStreamRingBytes - 1));
   const u32 lo = lds32(a), hi = lds32(a + 4);
   const u32 x = __builtin_amdgcn_alignbit(hi, lo, bit);
   const u32 full = (u32)__builtin_amdgcn_sbfe(b, 5, 1);  // all ones when b == 32
@@ -1029,129 +1184,301 @@ __device__ __forceinline__ void ring_eval_groups(const StreamPost& sp, const Unp
     for (u32 j = 0; j < 4; j++) v[j] = stream_post<PS>(sp, v[j], code_max);
     const u32 o1 = g * (btrfmt::FBP_GROUP * 4) + u.row4;
     const u32 o2 = (two ? g2 * (btrfmt::FBP_GROUP * 4) : 0x80000000u) + u.row4;  // out of range: dropped
-    __builtin_amdgcn_raw_buffer_store_b32(v[0], dst_rsrc, o1, 0, 0);
-    __builtin_amdgcn_raw_buffer_store_b32(v[1], dst_rsrc, o1 + 256, 0, 0);
-    __builtin_amdgcn_raw_buffer_store_b32(v[2], dst_rsrc, o2, 0, 0);
-    __builtin_amdgcn_raw_buffer_store_b32(v[3], dst_rsrc, o2 + 256, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b32(v[0], dst_rsrc, o1, 0, kStoreNt);
+    __builtin_amdgcn_raw_buffer_store_b32(v[1], dst_rsrc, o1 + 256, 0, kStoreNt);
+    __builtin_amdgcn_raw_buffer_store_b32(v[2], dst_rsrc, o2, 0, kStoreNt);
+    __builtin_amdgcn_raw_buffer_store_b32(v[3], dst_rsrc, o2 + 256, 0, kStoreNt);
   }
 }
 
-// One batch of the header chain, read from the ring (same stepping as walker_advance). Index
-// entries are {first payload word, header}.
-__device__ __forceinline__ void ring_walk_batch(u32 index_off, u32 t, u32 groups, u32& pos, u32& g, u32& bad_hdr) {
+// One batch of the header chain, read from the ring. Index entries are {first payload word, header}.
+template <u32 RING = 0>
+__device__ __forceinline__ void ring_walk_batch(u32 index_off, u32 jump_off, u32 t, u32 groups, ChainState& st,
+                                                u32& bad_hdr) {
   const u32 lane = threadIdx.x & 63;
   const u32 bb = t * kBatchWords;
-  const u32 slot = (t & (kRingBatches - 1)) * (kBatchWords * 4);
+  const u32 slot = RING + (t & (kRingBatches - 1)) * (kBatchWords * 4);
   u32 d[kWalkBatch];
 #pragma unroll
   for (u32 k = 0; k < kWalkBatch; k++)
     d[k] = group_lengths(*reinterpret_cast<const u32x4*>(lds_raw + slot + k * 1024 + lane * 16));
-  while (pos < bb + kBatchWords && g < groups) {
-    const u32 rel = pos - bb;
-    const u32 D = uniform(length_at(d, rel));
-    const u32 pj = rel + lane * D;
-    const bool inside = pj < kBatchWords;
-    const u32 dj = length_at(d, inside ? pj : rel);
-    const u64 ok = __ballot(inside && dj == D);
-    u32 m = (u32)__builtin_ctzll(~ok | (1ull << 63));
-    m = m == 63 && (ok >> 63) ? 64 : m;
-    m = m < groups - g ? m : groups - g;
-    if (lane < m) {
-      const u32 hv = ring_word(bb + pj);
+  walk_chain(d, bb, groups, jump_off, st, [&](u32 first, u32 count, u32 position) {
+    if (lane < count) {
+      const u32 hv = ring_word<RING>(position);
       if ((hv & 0xC0C0C0C0u) || ((hv + 0x5F5F5F5Fu) & 0x80808080u)) bad_hdr = 1;  // widths must be <= 32
-      lds_st64(index_off + 8 * (g + lane), ((u64)hv << 32) | (bb + pj + 1));
+      lds_st64(index_off + 8 * (first + lane), ((u64)hv << 32) | (position + 1));
     }
-    g = uniform(g + m);
-    pos = uniform(pos + m * D);
-  }
+  });
 }
 
-template <u32 PS>
-__device__ __forceinline__ void stream_int_bp(const Ctx& c, const Pipe& p, const IntEval& e, u32* __restrict__ dst) {
+// One pass of a bit-packed payload through the ring, by all waves of a 512-thread workgroup.
+// After walking a batch the walker stores publish(chain state) in LDS; in iteration t the unpack
+// waves get unpack(previous value, value after batch t, unpack wave number). With publish = groups
+// found, [lo, hi) are the groups that start in batch t: their words are in the ring (a group that
+// starts in batch t may run into batch t+1, which has landed) and their index entries are written.
+// Ends with the walker's tail decode and a workgroup barrier.
+template <typename Publish, typename Unpack>
+__device__ __forceinline__ void ring_pass(const Ctx& c, const Pipe& p, const BpView& bp, u32 jump_off, Publish publish,
+                                          Unpack unpack) {
   const u32 lane = threadIdx.x & 63, wave = uniform(threadIdx.x >> 6);
   const u32 W = uniform(p.a[1]), groups = uniform(p.a[5]);
-  const u32 index_off = e.bp.index_off;
   const u32 batches = (W + kBatchWords - 1) / kBatchWords;
-  const u32 found_off = c.red_off + 32;  // two LDS words: groups indexed after batch t, slot t & 1
+  const u32 slot_off = c.red_off + 32;  // two LDS words: published value after batch t, slot t & 1
 
   if (wave == kStreamWaves - 1) {
     // ---- loader
-    const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(e.bp.base, e.bp.bytes);
-    auto issue = [&](u32 t) {
-      if (t >= batches) return;
-      const u32 slot = (t & (kRingBatches - 1)) * (kBatchWords * 4);
-#pragma unroll
-      for (u32 k = 0; k < kWalkBatch; k++)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(
-            rsrc, (__attribute__((address_space(3))) void*)(lds_raw + slot + k * 1024), 16,
-            (t * kBatchWords + 256 * k + 4 * lane) * 4, 0, 0, 0);
-    };
-    // the word behind the ring follows ring word 0 (rewritten whenever a batch lands in slot 0)
-    auto mirror = [&]() {
-      if (lane == 0) lds_st32(kStreamRingBytes, lds32(0));
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    };
-    for (u32 t = 0; t < kRingAhead; t++) issue(t);
+    const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(bp.base, bp.bytes);
+    for (u32 t = 0; t < kRingAhead; t++) ring_issue<0>(rsrc, t, batches);
     // batches 0 and 1 landed (only batch 2 may still be in flight), then the start barrier
-    if (batches > 2)
-      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    mirror();
+    ring_wait(batches > 2);
+    ring_mirror<0>();
     __builtin_amdgcn_s_barrier();
     for (u32 t = 0; t < batches; t++) {
       // before barrier t: batch t+1 landed; at most batch t+2 stays in flight
-      if (t + 2 < batches)
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      else
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (((t + 1) & (kRingBatches - 1)) == 0) mirror();
+      ring_wait(t + 2 < batches);
+      if (((t + 1) & (kRingBatches - 1)) == 0) ring_mirror<0>();
       __builtin_amdgcn_s_barrier();
-      issue(t + kRingAhead);  // its slot held batch t-1, fully consumed before this barrier
+      ring_issue<0>(rsrc, t + kRingAhead, batches);  // its slot held batch t-1, fully consumed before this barrier
     }
   } else if (wave == 0) {
     // ---- walker: batch 0 before barrier 0, then batch t+1 during iteration t
-    u32 pos = 1, g = 0, bad_hdr = 0;
-    const u32 tail_word = load_tail_words(make_rsrc(e.bp.base, e.bp.bytes), W);
+    ChainState st{1, 0, 1};
+    u32 bad_hdr = 0;
+    const u32 tail_word = load_tail_words(make_rsrc(bp.base, bp.bytes), W);
+    __builtin_amdgcn_s_setprio(3);  // the chain is serial: keep it ahead of the unpackers
+    jump_tables_init(jump_off);
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    ring_walk_batch(index_off, 0, groups, pos, g, bad_hdr);
-    if (lane == 0) lds_st32(found_off, g);
+    ring_walk_batch(bp.index_off, jump_off, 0, groups, st, bad_hdr);
+    {
+      const u32 v = publish(st);
+      if (lane == 0) lds_st32(slot_off, v);
+    }
     for (u32 t = 0; t < batches; t++) {
       barrier_lds();
       if (t + 1 < batches) {
-        ring_walk_batch(index_off, t + 1, groups, pos, g, bad_hdr);
-        if (lane == 0) lds_st32(found_off + 4 * ((t + 1) & 1), g);
+        ring_walk_batch(bp.index_off, jump_off, t + 1, groups, st, bad_hdr);
+        const u32 v = publish(st);
+        if (lane == 0) lds_st32(slot_off + 4 * ((t + 1) & 1), v);
       }
     }
+    __builtin_amdgcn_s_setprio(0);
     // sentinel, flags and the VariableByte tail
-    walker_finish(WalkEnd{W, e.bp.rounded, groups, index_off, pos, g, __any(bad_hdr) ? 1u : 0u, tail_word}, c, p);
+    walker_finish(WalkEnd{W, bp.rounded, groups, bp.index_off, st.pos, st.g, __any(bad_hdr) ? 1u : 0u, tail_word}, c, p);
   } else {
-    // ---- unpackers: the groups that start in batch t, during iteration t
-    const UnpackLane u = unpack_lane();
-    const __amdgpu_buffer_rsrc_t dst_rsrc = make_rsrc(dst, e.bp.rounded * 4);
-    StreamPost sp;
-    sp.bias = e.post_bias[0];
-    sp.n = e.post_tab[0].count;
-    sp.dict_off = e.post_tab[0].lds;
-    sp.dict_g = make_rsrc(PS == PS_DICT_GLB ? e.post_tab[0].g : e.bp.base, PS == PS_DICT_GLB ? sp.n * 4 : 0);
-    u32 g_lo = 0, code_max = 0;
+    // ---- unpackers
+    u32 lo = 0;
     __builtin_amdgcn_s_barrier();
     for (u32 t = 0; t < batches; t++) {
       barrier_lds();
-      const u32 g_hi = uniform(lds32(found_off + 4 * (t & 1)));
-      ring_eval_groups<PS>(sp, u, dst_rsrc, index_off, g_lo, g_hi, wave - 1, code_max);
-      g_lo = g_hi;
+      const u32 hi = uniform(lds32(slot_off + 4 * (t & 1)));
+      unpack(lo, hi, wave - 1);
+      lo = hi;
     }
-    if ((PS == PS_DICT_LDS || PS == PS_DICT_GLB) && code_max >= sp.n) raise(c, ST_DICT_CODE);
   }
   __syncthreads();
+}
+
+template <u32 PS>
+__device__ __forceinline__ void stream_int_bp(const Ctx& c, const Pipe& p, const IntEval& e, u32* __restrict__ dst,
+                                              u32 jump_off) {
+  const UnpackLane u = unpack_lane();
+  const __amdgpu_buffer_rsrc_t dst_rsrc = make_rsrc(dst, e.bp.rounded * 4);
+  StreamPost sp;
+  sp.bias = e.post_bias[0];
+  sp.n = e.post_tab[0].count;
+  sp.dict_off = e.post_tab[0].lds;
+  sp.dict_g = make_rsrc(PS == PS_DICT_GLB ? e.post_tab[0].g : e.bp.base, PS == PS_DICT_GLB ? sp.n * 4 : 0);
+  u32 code_max = 0;
+  ring_pass(
+      c, p, e.bp, jump_off, [](const ChainState& st) { return st.g; },
+      [&](u32 g_lo, u32 g_hi, u32 uw) { ring_eval_groups<PS>(sp, u, dst_rsrc, e.bp.index_off, g_lo, g_hi, uw, code_max); });
+  if ((PS == PS_DICT_LDS || PS == PS_DICT_GLB) && code_max >= sp.n) raise(c, ST_DICT_CODE);
   {
     u32 bad = 0;
     for (u32 i = e.bp.rounded + threadIdx.x; i < e.count; i += kStreamThreads)
       dst[i] = apply_posts<PS>(e, lds32(e.bp.tail_off + 4 * ((i - e.bp.rounded) & 31)), bad);
     report(c, bad);
   }
+}
+
+// ---- PSEUDODECIMAL(BP, BP, raw patches): digits streamed through the ring -------------------------
+// double/Pseudodecimal.cpp:424-436: row i is patches[x] when its exponent is the exception code
+// (x = exceptions before row i), else double(int32 digits[i - x]) * 10^-exponent. The digit
+// stream is the wide one and goes through the LDS ring exactly like a bit-packed integer root;
+// the exponents (a few bits per row) were indexed and scanned for exception codes by the
+// preparation steps and are bit-unpacked from global memory, where they stay cache resident.
+// Rows are produced in 128-row groups of the exponent stream; the digit of a row is gathered per
+// lane from wherever it sits in the ring. After each batch the walker converts "digits indexed
+// so far" into "rows that can be produced" by a select on the exception bitmap.
+__device__ __forceinline__ u64 pseudo_value(u32 digits, u32 ex, u32 frac_off, u32& exbad) {
+  u32 idx = ex & btrfmt::DEC_INDEX_MASK;
+  exbad |= (ex != btrfmt::DEC_EXCEPTION_CODE && idx > btrfmt::DEC_MAX_EXPONENT) ? 2u : 0u;
+  idx = idx > btrfmt::DEC_MAX_EXPONENT ? btrfmt::DEC_MAX_EXPONENT : idx;
+  const double f = __longlong_as_double((long long)lds64(frac_off + 8 * idx));
+  return (u64)__double_as_longlong((double)(int)digits * f);
+}
+
+// Same extraction as ring_extract, from global memory (generic index entry: header position).
+__device__ __forceinline__ u32 global_extract(__amdgpu_buffer_rsrc_t rsrc, u32 first, u32 hdr, u32 sh, u32 pm, u32 k) {
+  const u32 b = __builtin_amdgcn_ubfe(hdr, sh, 8);
+  const u32 w = __builtin_amdgcn_sad_u8(hdr & pm, 0u, first);
+  const u32 bit = __umul24(k, b);
+  const u32x2 ww = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (w + (bit >> 5)) * 4, 0, 0);
+  const u32 x = __builtin_amdgcn_alignbit(ww.y, ww.x, bit);
+  const u32 full = (u32)__builtin_amdgcn_sbfe(b, 5, 1);
+  return __builtin_amdgcn_ubfe(x, 0u, b) | (x & full);
+}
+
+// First row that needs digit number `target` or a later one: the position of the target-th
+// clear bit of the exception bitmap (rows before it only use digits below target), or `n` when
+// there are not that many. One wave; words = n / 64 + 1 <= 4096.
+__device__ __forceinline__ u32 select_clear(const RankView& rk, u32 words, u32 n, u32 target) {
+  const u32 lane = threadIdx.x & 63;
+  const u32 stride = (words + 63) / 64;
+  auto clear_before = [&](u32 w) { return 64 * w - lds32(rk.rank_off + 4 * w); };
+  // largest word w with clear_before(w) <= target, in two 64-way steps
+  const u32 w1 = lane * stride;
+  const u32 c1 = (u32)__popcll(__ballot(w1 < words && clear_before(w1 < words ? w1 : 0) <= target));
+  const u32 ws = (c1 ? c1 - 1 : 0) * stride;
+  const u32 w2 = ws + lane;
+  const u32 c2 = (u32)__popcll(__ballot(lane < stride && w2 < words && clear_before(w2 < words ? w2 : 0) <= target));
+  const u32 w = uniform(ws + (c2 ? c2 - 1 : 0));
+  const u32 rem = target - uniform(clear_before(w));
+  const u64 inv = ~lds64(rk.bits_off + 8 * w);
+  const bool hit = ((inv >> lane) & 1) && (u32)__popcll(inv & ((1ull << lane) - 1)) == rem;
+  const u64 m = __ballot(hit);
+  const u32 r = m ? 64 * w + (u32)__builtin_ctzll(m) : n;
+  return r < n ? r : n;
+}
+
+// Exception flags of the exponent stream: one ring pass whose unpackers turn every 64 rows into a
+// bitmap word (row i is set when its exponent is the exception code). Builds the stream-format
+// group index of the exponents on the way.
+__device__ __forceinline__ void stream_exception_bits(const Ctx& c, const Pipe& pe, const BpView& be, const RankView& rk,
+                                                      u32 words, u32 n, u32 jump_off) {
+  const UnpackLane u = unpack_lane();
+  const u32 lane = threadIdx.x & 63;
+  ring_pass(
+      c, pe, be, jump_off, [](const ChainState& st) { return st.g; },
+      [&](u32 g_lo, u32 g_hi, u32 uw) {
+        for (u32 G = g_lo + uw; G < g_hi; G += kUnpackWaves) {
+          const u64 ee = lds64(be.index_off + 8 * G);
+          const u32 x0 = ring_extract<0>((u32)ee, (u32)(ee >> 32), u.sh_lo, u.pm_lo, u.k);
+          const u32 x1 = ring_extract<0>((u32)ee, (u32)(ee >> 32), u.sh_hi, u.pm_hi, u.k);
+          const u32 i0 = G * btrfmt::FBP_GROUP + lane, i1 = i0 + 64;
+          const u64 m0 = __ballot(i0 < be.rounded && x0 == btrfmt::DEC_EXCEPTION_CODE);
+          const u64 m1 = __ballot(i1 < be.rounded && x1 == btrfmt::DEC_EXCEPTION_CODE);
+          if (lane == 0) {
+            if (2 * G < words) lds_st64(rk.bits_off + 16 * G, m0);
+            if (2 * G + 1 < words) lds_st64(rk.bits_off + 16 * G + 8, m1);
+          }
+        }
+      });
+  // rows of the VariableByte tail (decoded by the walker at the end of the pass)
+  if (threadIdx.x < 32) {
+    const u32 i = be.rounded + threadIdx.x;
+    if (i < n && lds32(be.tail_off + 4 * threadIdx.x) == btrfmt::DEC_EXCEPTION_CODE) bitmap_or(rk.bits_off, i);
+  }
+  __syncthreads();
+}
+
+__device__ __forceinline__ void stream_pseudo(const Ctx& c, const Pipe& root, const Pipe& pd, const Pipe& pe,
+                                              const RankView& rk, u64* __restrict__ dst, u32 frac_off, u32 jump_off) {
+  const u32 lane = threadIdx.x & 63;
+  const BpView bd = resolve_bp(c, pd), be = resolve_bp(c, pe);
+  const Tab patches = resolve_tab(c, uniform(root.a[2]));
+  const u32 n = uniform(root.count);
+  const u32 words = n / 64 + 1;
+  const u32 groups_e = uniform(pe.a[5]);
+  const __amdgpu_buffer_rsrc_t rsrc_d = make_rsrc(bd.base, bd.bytes), rsrc_e = make_rsrc(be.base, be.bytes);
+  const __amdgpu_buffer_rsrc_t dst_rsrc = make_rsrc(dst, n * 8);
+  const UnpackLane u = unpack_lane();
+  u32 exbad = 0;
+  u32 row_end = 0;  // rows the pass could produce (walker wave only; shared through LDS below)
+
+  ring_pass(
+      c, pd, bd, jump_off,
+      [&](const ChainState& st) {
+        // digits indexed so far -> rows that can be produced
+        const u32 digits_ready = st.g * btrfmt::FBP_GROUP < bd.rounded ? st.g * btrfmt::FBP_GROUP : bd.rounded;
+        u32 r = select_clear(rk, words, n, digits_ready);
+        r = r < be.rounded ? r : be.rounded;
+        row_end = r;
+        return r;
+      },
+      [&](u32 r_lo, u32 r_hi, u32 uw) {
+        // rows [r_lo, r_hi) by 128-row groups of the exponent stream, two groups per iteration:
+        // their four exponent loads are in flight together
+        for (u32 G0 = (r_lo >> 7) + uw; G0 * btrfmt::FBP_GROUP < r_hi; G0 += 2 * kUnpackWaves) {
+          u32 x[2][2];
+#pragma unroll
+          for (u32 j = 0; j < 2; j++) {
+            const u32 G = G0 + j * kUnpackWaves;  // a group behind r_hi only yields dropped stores
+            const u64 ee = lds64(be.index_off + 8 * (G < groups_e ? G : G0));
+            x[j][0] = global_extract(rsrc_e, (u32)ee, (u32)(ee >> 32), u.sh_lo, u.pm_lo, u.k);
+            x[j][1] = global_extract(rsrc_e, (u32)ee, (u32)(ee >> 32), u.sh_hi, u.pm_hi, u.k);
+          }
+#pragma unroll
+          for (u32 j = 0; j < 2; j++) {
+            const u32 G = G0 + j * kUnpackWaves;
+            const u32 Gc = G < groups_e ? G : G0;
+            const u64 m0 = lds64(rk.bits_off + 16 * Gc), m1 = lds64(rk.bits_off + 16 * Gc + 8);
+            const u32 xr0 = __builtin_amdgcn_mbcnt_hi((u32)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((u32)m0, lds32(rk.rank_off + 8 * Gc)));
+            const u32 xr1 = __builtin_amdgcn_mbcnt_hi((u32)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((u32)m1, lds32(rk.rank_off + 8 * Gc + 4)));
+            const u32 i0 = G * btrfmt::FBP_GROUP + lane, i1 = i0 + 64;
+            u64 r[2];
+#pragma unroll
+            for (u32 h = 0; h < 2; h++) {
+              const u32 xv = x[j][h], xr = h ? xr1 : xr0, i = h ? i1 : i0;
+              const u32 di = i - xr;
+              const u64 ed = lds64(bd.index_off + 8 * (di >> 7));
+              const u32 m = (di >> 5) & 3;
+              const u32 dv = ring_extract<0>((u32)ed, (u32)(ed >> 32), 24 - 8 * m, ~(0xFFFFFFFFu >> (8 * m)), di & 31);
+              r[h] = pseudo_value(dv, xv, frac_off, exbad);
+              if (xv == btrfmt::DEC_EXCEPTION_CODE) r[h] = xr < patches.count ? ldg64(patches.g + 8ull * xr) : 0;
+            }
+            const u32 o0 = (i0 >= r_lo && i0 < r_hi) ? i0 * 8 : 0x80000000u;  // out of range: dropped
+            const u32 o1 = (i1 >= r_lo && i1 < r_hi) ? i1 * 8 : 0x80000000u;
+            u32x2 s0, s1;
+            s0.x = (u32)r[0], s0.y = (u32)(r[0] >> 32), s1.x = (u32)r[1], s1.y = (u32)(r[1] >> 32);
+            __builtin_amdgcn_raw_buffer_store_b64(s0, dst_rsrc, o0, 0, kStoreNt);
+            __builtin_amdgcn_raw_buffer_store_b64(s1, dst_rsrc, o1, 0, kStoreNt);
+          }
+        }
+      });
+  // rows behind the last one the pass could produce: digits or exponents from the tails
+  const u32 end_off = c.red_off + 32;
+  if (threadIdx.x == 0) lds_st32(end_off, row_end);
+  __syncthreads();
+  row_end = uniform(lds32(end_off));
+  for (u32 i = row_end + threadIdx.x; i < n; i += kStreamThreads) {
+    u32 x;
+    if (i >= be.rounded) {
+      x = lds32(be.tail_off + 4 * ((i - be.rounded) & 31));
+    } else {
+      const u64 ee = lds64(be.index_off + 8 * (i >> 7));
+      const u32 m = (i >> 5) & 3;
+      x = global_extract(rsrc_e, (u32)ee, (u32)(ee >> 32), 24 - 8 * m, ~(0xFFFFFFFFu >> (8 * m)), i & 31);
+    }
+    bool member;
+    const u32 xr = rank_lt(rk, i, &member);
+    const u32 di = i - xr;
+    u32 dv = 0;
+    if (x != btrfmt::DEC_EXCEPTION_CODE) {
+      if (di >= bd.rounded) {
+        dv = lds32(bd.tail_off + 4 * ((di - bd.rounded) & 31));
+      } else {
+        const u64 ed = lds64(bd.index_off + 8 * (di >> 7));
+        const u32 m = (di >> 5) & 3;
+        dv = global_extract(rsrc_d, (u32)ed, (u32)(ed >> 32), 24 - 8 * m, ~(0xFFFFFFFFu >> (8 * m)), di & 31);
+      }
+    }
+    u64 r = pseudo_value(dv, x, frac_off, exbad);
+    if (x == btrfmt::DEC_EXCEPTION_CODE) r = xr < patches.count ? ldg64(patches.g + 8ull * xr) : 0;
+    dst[i] = r;
+  }
+  if (exbad & 2) raise(c, ST_EXPONENT);
 }
 
 template <u32 BASE, u32 IA, u32 IB, u32 IPS>
@@ -1243,14 +1570,12 @@ __device__ __forceinline__ void materialize(const Ctx& c, u32 pipe_id, u32 seq_i
 }
 
 // ---- bitmap steps ----------------------------------------------------------------------------------
-__device__ __forceinline__ void bitmap_or(u32 bits_off, u32 row) {
-  atomicOr(reinterpret_cast<u32*>(lds_raw + bits_off + 4 * (row >> 5)), 1u << (row & 31));
-}
 
+template <u32 THREADS = kBlockThreads>
 __device__ __forceinline__ void bitmap_clear(const Ctx& c, const Step& s) {
   const Seq& bm = seq_at(c, uniform(s.a[1]));
   const u32 off = c.table_base + uniform(bm.off), words = uniform(bm.count) * 2;
-  for (u32 w = threadIdx.x; w < words; w += kBlockThreads) lds_st32(off + 4 * w, 0);
+  for (u32 w = threadIdx.x; w < words; w += THREADS) lds_st32(off + 4 * w, 0);
 }
 
 // Members of one CRoaring container (or of the whole bitmap for the u32-array form) -> bits.
@@ -1341,34 +1666,64 @@ __device__ __forceinline__ void bitmap_starts(const Ctx& c, const Step& s) {
 }
 
 // bit i = (pipe[i] == value); each wave writes the 64-bit ballot of its 64 consecutive rows.
+// A bare bit-packed pipe is scanned a 128-value group per wave, two groups (four loads) in flight.
+template <u32 THREADS = kBlockThreads>
 __device__ __forceinline__ void bitmap_eq(const Ctx& c, const Step& s) {
   const IntEval e = resolve_int(c, uniform(s.a[0]));
-  const u32 bits_off = seq_lds(c, uniform(s.a[1]));
+  const Seq& bm = seq_at(c, uniform(s.a[1]));
+  const u32 bits_off = c.table_base + uniform(bm.off), words = uniform(bm.count);
   const u32 nbits = uniform(s.a[3]), value = uniform(s.a[4]);
+  const u32 lane = threadIdx.x & 63, wave = uniform(threadIdx.x >> 6);
+  if (e.base == B_BP && e.n_post == 0) {
+    const UnpackLane u = unpack_lane();
+    const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(e.bp.base, e.bp.bytes);
+    const u32 groups = (nbits + btrfmt::FBP_GROUP - 1) / btrfmt::FBP_GROUP;
+    for (u32 G0 = 2 * wave; G0 < groups; G0 += 2 * (THREADS / 64)) {
+      u32 x[2][2];
+#pragma unroll
+      for (u32 j = 0; j < 2; j++) {
+        const u32 G = G0 + j < groups ? G0 + j : G0;
+        const u64 en = lds64(e.bp.index_off + 8 * G);
+        x[j][0] = global_extract(rsrc, (u32)en + 1, (u32)(en >> 32), u.sh_lo, u.pm_lo, u.k);
+        x[j][1] = global_extract(rsrc, (u32)en + 1, (u32)(en >> 32), u.sh_hi, u.pm_hi, u.k);
+      }
+#pragma unroll
+      for (u32 j = 0; j < 2; j++) {
+#pragma unroll
+        for (u32 h = 0; h < 2; h++) {
+          const u32 i = (G0 + j) * btrfmt::FBP_GROUP + 64 * h + lane;
+          const u32 v = i >= e.bp.rounded ? lds32(e.bp.tail_off + 4 * ((i - e.bp.rounded) & 31)) : x[j][h];
+          const u64 m = __ballot(i < nbits && v == value);
+          if (lane == 0 && G0 + j < groups && (i >> 6) < words) lds_st64(bits_off + 8 * (i >> 6), m);
+        }
+      }
+    }
+    return;
+  }
   u32 bad = 0;
-  for (u32 base = 0; base < nbits; base += kBlockThreads) {
+  for (u32 base = 0; base < nbits; base += THREADS) {
     const u32 i = base + threadIdx.x;
     const u32 ii = i < nbits ? i : nbits - 1;
-    const u32 v = (e.base == B_BP && e.n_post == 0) ? eval_int<B_BP, true, PS_NONE>(e, ii, bad)
-                                                     : eval_int<GEN, true, PS_GEN>(e, ii, bad);
+    const u32 v = eval_int<GEN, true, PS_GEN>(e, ii, bad);
     const u64 m = __ballot(i < nbits && v == value);
-    if ((threadIdx.x & 63) == 0 && (i >> 6) <= (nbits >> 6)) lds_st64(bits_off + 8 * (i >> 6), m);
+    if (lane == 0 && (i >> 6) <= (nbits >> 6)) lds_st64(bits_off + 8 * (i >> 6), m);
   }
   report(c, bad);
 }
 
 // rank[w] = set bits in words [0, w): every thread owns a contiguous slice of words.
+template <u32 THREADS = kBlockThreads>
 __device__ __forceinline__ void bitmap_rank(const Ctx& c, const Step& s) {
   const Seq& bm = seq_at(c, uniform(s.a[1]));
   const u32 bits_off = c.table_base + uniform(bm.off), words = uniform(bm.count);
   const u32 rank_off = seq_lds(c, uniform(s.a[2]));
-  const u32 per = (words + kBlockThreads - 1) / kBlockThreads;
+  const u32 per = (words + THREADS - 1) / THREADS;
   const u32 w_lo = threadIdx.x * per < words ? threadIdx.x * per : words;
   const u32 w_hi = w_lo + per < words ? w_lo + per : words;
   u32 sum = 0;
   for (u32 w = w_lo; w < w_hi; w++) sum += __popcll(lds64(bits_off + 8 * w));
   u32 total;
-  u32 before = block_exclusive_scan(c, sum, &total);
+  u32 before = block_exclusive_scan<THREADS>(c, sum, &total);
   for (u32 w = w_lo; w < w_hi; w++) {
     lds_st32(rank_off + 4 * w, before);
     before += __popcll(lds64(bits_off + 8 * w));
@@ -1444,7 +1799,39 @@ __device__ __forceinline__ void stream_block(const WorkItem* __restrict__ items,
   const Step& root = step_at(c, hdr.n_steps - 1);
   const u32 pipe_id = uniform(root.a[0]);
   const IntEval e = resolve_int(c, pipe_id);
-  stream_int_bp<PS>(c, pipe_at(c, pipe_id), e, reinterpret_cast<u32*>(c.dst));
+  stream_int_bp<PS>(c, pipe_at(c, pipe_id), e, reinterpret_cast<u32*>(c.dst), seq_lds(c, uniform(root.a[3])));
+}
+
+// PSEUDODECIMAL(BP, BP, raw patches) chunks. The program is [clear bitmap, rank, streamed root]:
+// the exception bitmap is filled by a ring pass over the exponent stream between the first two.
+__device__ __forceinline__ void stream_pseudo_block(const WorkItem* __restrict__ items, const u32* __restrict__ order,
+                                                    const u8* __restrict__ programs, u32* __restrict__ status) {
+  const u32 item = order[blockIdx.x];
+  const WorkItem it = items[item];
+  Ctx c;
+  stamp(it, 0);
+  const ProgramHeader hdr = load_program<kStreamThreads, kStreamProgBase>(it, item, programs, status, c);
+  stamp(it, 1);
+  const Step& root = step_at(c, hdr.n_steps - 1);
+  const Pipe& rp = pipe_at(c, uniform(root.a[0]));
+  const Pipe& pd = pipe_at(c, uniform(rp.a[0]));
+  const Pipe& pe = pipe_at(c, uniform(rp.a[1]));
+  const u32 frac_off = seq_lds(c, uniform(root.a[2])), jump_off = seq_lds(c, uniform(root.a[3]));
+  RankView rk;
+  rk.bits_off = seq_lds(c, uniform(rp.a[3]));
+  rk.rank_off = seq_lds(c, uniform(rp.a[4]));
+  const u32 n = uniform(rp.count);
+  if (threadIdx.x < 23) lds_st64(frac_off + 8 * threadIdx.x, (u64)__double_as_longlong(kFractions[threadIdx.x]));
+  bitmap_clear<kStreamThreads>(c, step_at(c, 0));
+  __syncthreads();
+  stamp(it, 2);
+  stream_exception_bits(c, pe, resolve_bp(c, pe), rk, n / 64 + 1, n, jump_off);
+  stamp(it, 3);
+  bitmap_rank<kStreamThreads>(c, step_at(c, 1));
+  __syncthreads();
+  stamp(it, 4);
+  stream_pseudo(c, rp, pd, pe, rk, reinterpret_cast<u64*>(c.dst), frac_off, jump_off);
+  stamp(it, 5);
 }
 
 template <bool DOUBLE_KERNEL>
@@ -1461,7 +1848,7 @@ __device__ __forceinline__ void decode_block(const WorkItem* __restrict__ items,
   // bit-unpack indexes: one stream per wave, streams in parallel
   if (!(it.debug_flags & 5))
     for (u32 s = uniform(tid >> 6); s < hdr.n_bp_steps; s += kBlockThreads / 64)
-      bp_index_wave(c, pipe_at(c, uniform(step_at(c, s).a[0])));
+      bp_index_wave(c, step_at(c, s));
   __syncthreads();
   stamp(it, 2);
 
@@ -1521,4 +1908,10 @@ extern "C" __global__ void __launch_bounds__(kStreamThreads)
 btr_stream_dict_glb_kernel(const WorkItem* __restrict__ items, const u32* __restrict__ order,
                            const u8* __restrict__ programs, u32* __restrict__ status) {
   stream_block<PS_DICT_GLB>(items, order, programs, status);
+}
+// PSEUDODECIMAL(BP, BP, raw patches) double columns (plan.h: KERNEL_STREAM_PSEUDO).
+extern "C" __global__ void __launch_bounds__(kStreamThreads)
+btr_stream_pseudo_kernel(const WorkItem* __restrict__ items, const u32* __restrict__ order,
+                         const u8* __restrict__ programs, u32* __restrict__ status) {
+  stream_pseudo_block(items, order, programs, status);
 }

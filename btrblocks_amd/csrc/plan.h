@@ -72,7 +72,8 @@ struct Pipe {
 };
 
 enum : uint8_t {
-  S_BP_INDEX = 0,       // a0 pipe id: walk the group headers of a B_BP/B_DBP stream, decode its tail
+  S_BP_INDEX = 0,       // a0 pipe id: walk the group headers of a B_BP/B_DBP stream, decode its tail;
+                        // a1 seq id of kWalkScratchBytes of LDS for the walker's jump tables (or NONE)
   S_MATERIALIZE = 1,    // a0 pipe id, a1 dst seq id
   S_BITMAP_CLEAR = 2,   // a1 seq bitmap
   S_BITMAP_SET = 3,     // a0 src byte offset, a1 seq bitmap, a2 element count, a3 first row of the
@@ -83,8 +84,9 @@ enum : uint8_t {
   S_BITMAP_RANK = 6,    // a1 seq bitmap, a2 seq rank, a3 bit count, a4 expected popcount (or NONE),
                         // a5 status bit to raise on a mismatch
   S_NULLMAP = 7,        // a0 nullmap type, a1 seq bitmap (REGULAR/FLIPPED, else NONE), a3 row count
-  S_STREAM_ROOT = 8,    // a0 pipe id (B_BP base), a1 dst seq id: root step that stages the payload through
-                        // an LDS ring at the start of LDS, indexing and unpacking it batch by batch
+  S_STREAM_ROOT = 8,    // a0 pipe id (B_BP or B_PSEUDO base), a1 dst seq id, a2 seq id of the powers-of-ten
+                        // table (B_PSEUDO), a3 seq id of the walker's jump tables: root step that stages the payload(s) through LDS rings,
+                        // indexing and unpacking them batch by batch
 };
 // Element kinds of S_BITMAP_SET: the four member encodings of CRoaring's native serialization.
 enum : uint32_t { SET_ARRAY32 = 0, SET_ARRAY16 = 1, SET_BITSET = 2, SET_RUNS = 3 };
@@ -141,7 +143,8 @@ enum : uint32_t {
   KERNEL_STREAM_ADD = 3,       // FOR(BP)
   KERNEL_STREAM_DICT_LDS = 4,  // DICT(BP), dictionary staged in LDS
   KERNEL_STREAM_DICT_GLB = 5,  // DICT(BP), dictionary read from the compressed bytes
-  KERNEL_KINDS = 6,
+  KERNEL_STREAM_PSEUDO = 6,    // PSEUDODECIMAL(BP,BP,raw patches) doubles: digits through the ring
+  KERNEL_KINDS = 7,
 };
 
 constexpr uint32_t kBlockThreads = 256;
@@ -149,6 +152,10 @@ constexpr uint32_t kStreamRingBytes = 16 * 1024;  // LDS ring of the streamed ro
 // The stream kernels keep the ring at LDS offset 0 (ring addresses are then a plain mask), one
 // mirror word behind it, and the program copy after that.
 constexpr uint32_t kStreamProgBase = kStreamRingBytes + 16;
+// LDS scratch of one header-chain walker: a table of (1024 + 256) 16-bit jump pointers.
+constexpr uint32_t kWalkScratchBytes = (1024 + 256) * 2;
+// Streams with more groups than this get jump tables; shorter ones are walked without.
+constexpr uint32_t kWalkScratchMinGroups = 64;
 constexpr uint32_t kLdsCapBytes = 160 * 1024;  // all of a gfx950 CU's LDS; typical chunks need 5-40 KiB
 
 }  // namespace btrplan

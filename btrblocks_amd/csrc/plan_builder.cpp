@@ -28,7 +28,7 @@ constexpr int ST_CORRUPT = 2, ST_UNSUPPORTED = 3, ST_MISALIGNED = 6;
 constexpr int kMaxDepth = 8;
 // Optional tables (materialized children, dictionary copies) go to LDS while the workgroup's
 // total stays under this; beyond it they live in the chunk's HBM scratch slice.
-constexpr uint32_t kLdsSoftCap = 40 * 1024;
+constexpr uint32_t kLdsSoftCap = 52 * 1024;  // three workgroups per CU
 constexpr uint32_t kDictLdsMaxBytes = 32 * 1024;
 
 struct Builder {
@@ -496,9 +496,38 @@ void build_program(const ColumnSource& src, BuiltProgram& out) {
         kernel = KERNEL_STREAM_ADD;
       else
         kernel = KERNEL_STREAM_DICT_LDS;  // corrected below once table placement is known
+    } else if (src.column_type == COL_DOUBLE && rp.base == B_PSEUDO && rp.a[0] != NONE && !src.want_nullmap &&
+               n > 0 && n / 64 + 1 <= 4096 && bld.bp_steps.size() == 2 && bld.steps.size() == 3 &&
+               bld.pipes[rp.a[0]].base == B_BP && bld.pipes[rp.a[0]].n_post == 0 &&
+               bld.pipes[rp.a[1]].base == B_BP && bld.pipes[rp.a[1]].n_post == 0 &&
+               (rp.a[2] == NONE || bld.seqs[rp.a[2]].loc == LOC_SRC)) {
+      // PSEUDODECIMAL(BP,BP) with raw (or no) patches: both streams go through the LDS ring, the
+      // exponents first (exception flags into the bitmap the pipe already owns), then the digits.
+      // The program keeps the clear and rank steps; the kernel does the exponent pass in between.
+      bld.bp_steps.clear();
+      std::vector<Step> keep;
+      for (const Step& st : bld.steps)
+        if (st.kind != S_BITMAP_EQ) keep.push_back(st);
+      bld.steps = keep;
+      const uint32_t fractions = bld.add_seq(LOC_LDS, 0, DEC_MAX_EXPONENT + 1, 8, true);
+      bld.add_step(S_STREAM_ROOT, root, dst, fractions);
+      prog_base = kStreamProgBase;
+      kernel = KERNEL_STREAM_PSEUDO;
     } else {
       bld.add_step(S_MATERIALIZE, root, dst);
     }
+  }
+  // LDS scratch for the header-chain walkers: index step s runs on wave s % 4, so four slots
+  // cover every program; the streamed root's walker starts after the index steps and reuses slot 0.
+  uint32_t walk_scratch[4] = {NONE, NONE, NONE, NONE};
+  {
+    auto scratch_slot = [&](size_t k) {
+      if (walk_scratch[k] == NONE) walk_scratch[k] = bld.add_seq(LOC_LDS, 0, kWalkScratchBytes / 16, 16, true);
+      return walk_scratch[k];
+    };
+    for (size_t k = 0; k < bld.bp_steps.size(); k++)
+      if (bld.pipes[bld.bp_steps[k].a[0]].a[5] > kWalkScratchMinGroups) bld.bp_steps[k].a[1] = scratch_slot(k % 4);
+    if (kernel != KERNEL_GENERIC_INT && kernel != KERNEL_GENERIC_DBL) bld.steps.back().a[3] = scratch_slot(0);
   }
   if (src.want_nullmap) {
     if (src.nullmap_type == NM_REGULAR || src.nullmap_type == NM_FLIPPED) {
@@ -524,6 +553,21 @@ void build_program(const ColumnSource& src, BuiltProgram& out) {
       s.off = (uint32_t)lds;
       lds += align_up(s.count * s.esize, 16);
     }
+  if (table_base + lds > kLdsCapBytes && kernel <= KERNEL_GENERIC_DBL) {
+    // very large blocks: give up the walkers' jump tables (they only speed the index steps up)
+    for (uint32_t k = 0; k < 4; k++)
+      if (walk_scratch[k] != NONE) {
+        lds -= align_up(bld.seqs[walk_scratch[k]].count * bld.seqs[walk_scratch[k]].esize, 16);
+        bld.seqs[walk_scratch[k]].count = 0;
+      }
+    for (Step& st : bld.bp_steps) st.a[1] = NONE;
+    lds = 0;
+    for (auto& s : bld.seqs)
+      if (s.loc == LOC_LDS && s.must_lds) {
+        s.off = (uint32_t)lds;
+        lds += align_up(s.count * s.esize, 16);
+      }
+  }
   for (auto& s : bld.seqs)
     if (s.loc == LOC_LDS && !s.must_lds) {
       const uint64_t bytes = align_up(s.count * s.esize, 16);
