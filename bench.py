@@ -201,14 +201,28 @@ def main():
             "alg_bytes_per_value": round(ab / s.tuples, 3),
             "lds_bytes": int(s.max_lds_bytes),
         }
-    achieved = alg_bytes / (mean_ms.sum() / 1e3) / 1e9  # GB/s over the kernel's launches
+    # kernel behind each plan (one launch per plan in this workload)
+    from btrblocks_amd import _native
+    lib = _native.load()
+
+    def kernel_names(mask):
+        return [lib.btr_kernel_name(k).decode() for k in range(32) if mask >> k & 1]
+
+    for i, c in enumerate(cols):
+        per_column[c["name"]]["kernels"] = kernel_names(stats[i].kernel_mask)
+    # the dominant kernel: the launch that takes the largest share of a step
+    dom = int(np.argmax(mean_ms))
+    dom_alg = stats[dom].decoded_bytes + stats[dom].needed_bytes
+    achieved = dom_alg / (mean_ms[dom] / 1e3) / 1e9          # GB/s of the dominant kernel's launches
+    achieved_all = alg_bytes / (mean_ms.sum() / 1e3) / 1e9   # GB/s over all launches of a step
 
     if rank == 0:
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("bytes_per_launch")
+                traffic = json.load(open(tpath)).get("bytes_per_launch", {}).get(
+                    per_column[cols[dom]["name"]]["kernels"][0])
             except Exception:
                 traffic = None
         line = {
@@ -239,10 +253,13 @@ def main():
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": traffic,
-                "kernel": "btr_decode_kernel",
-                "launches_per_step": len(plans),
-                "alg_bytes_per_step": int(alg_bytes),
-                "avg_launch_ms": round(float(mean_ms.mean()), 4),
+                "kernel": ",".join(per_column[cols[dom]["name"]]["kernels"]),
+                "column": cols[dom]["name"],
+                "alg_bytes_per_launch": int(dom_alg),
+                "avg_launch_ms": round(float(mean_ms[dom]), 4),
+                "all_launches": {"achieved": round(achieved_all, 1), "frac": round(achieved_all / HBM_PEAK_GBS, 4),
+                                 "launches_per_step": int(sum(s.launches for s in stats)),
+                                 "alg_bytes_per_step": int(alg_bytes), "kernel_ms_per_step": round(float(mean_ms.sum()), 4)},
                 "per_column": per_column,
             },
             "host": {

@@ -81,6 +81,8 @@ class PlanStats(C.Structure):
         ("scratch_bytes", C.c_uint64),
         ("max_lds_bytes", C.c_uint32),
         ("max_depth", C.c_uint32),
+        ("kernel_mask", C.c_uint32),
+        ("launches", C.c_uint32),
     ]
 
 
@@ -111,6 +113,7 @@ SIGNATURES = {
                                                 C.c_uint32, C.POINTER(_P)]),
     "btr_gpu_plan_destroy": (None, [_P]),
     "btr_gpu_plan_stats": (C.c_int, [_P, C.POINTER(PlanStats)]),
+    "btr_kernel_name": (C.c_char_p, [C.c_uint32]),
     "btr_gpu_decode": (C.c_int, [_P, _P, _P]),
     "btr_gpu_plan_check": (C.c_int, [_P, _P, _P, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]),
     "btr_gpu_decode_chunk_host": (C.c_int, [_P, _P, C.c_size_t, _P, C.c_size_t, _P]),

@@ -209,6 +209,11 @@ btr_status finish_plan(btr_gpu_ctx* ctx, std::vector<WorkItem>& items, std::vect
         }
     }
     plan->kind_begin[KERNEL_KINDS] = order.size();
+    for (uint32_t kind = 0; kind < KERNEL_KINDS; kind++)
+      if (plan->kind_begin[kind + 1] > plan->kind_begin[kind]) {
+        plan->stats.kernel_mask |= 1u << kind;
+        plan->stats.launches++;
+      }
     if ((e = hipMalloc((void**)&plan->d_order, order.size() * 4)) != hipSuccess)
       return cleanup(hip_fail(e, "hipMalloc(order)"));
     if ((e = hipMemcpy(plan->d_order, order.data(), order.size() * 4, hipMemcpyHostToDevice)) != hipSuccess)
@@ -224,6 +229,12 @@ extern "C" {
 
 const char* btr_last_error(void) { return g_error.c_str(); }
 const char* btr_version(void) { return "btrblocks_amd 0.1 (gfx950)"; }
+const char* btr_kernel_name(uint32_t k) {
+  static const char* const names[KERNEL_KINDS] = {
+      "btr_decode_int_kernel",      "btr_decode_dbl_kernel",      "btr_stream_none_kernel",  "btr_stream_add_kernel",
+      "btr_stream_dict_lds_kernel", "btr_stream_dict_glb_kernel", "btr_stream_pseudo_kernel"};
+  return k < KERNEL_KINDS ? names[k] : nullptr;
+}
 
 // ---- inspection -------------------------------------------------------------------------------
 btr_status btr_chunk_inspect(const void* chunk, size_t bytes, btr_chunk_info* out) {

@@ -147,8 +147,13 @@ typedef struct btr_plan_stats {
   uint64_t scratch_bytes;    /* HBM scratch for tables that did not fit in LDS                  */
   uint32_t max_lds_bytes;    /* dynamic LDS per workgroup                                       */
   uint32_t max_depth;
+  uint32_t kernel_mask;      /* bit k set: the plan launches kernel k (see btr_kernel_name)     */
+  uint32_t launches;         /* kernel launches per btr_gpu_decode                              */
 } btr_plan_stats;
 btr_status btr_gpu_plan_stats(const btr_gpu_plan* plan, btr_plan_stats* out);
+/* Name of the HIP kernel behind bit k of btr_plan_stats::kernel_mask (as profilers show it), or
+ * NULL when k is out of range. */
+const char* btr_kernel_name(uint32_t k);
 
 /* Enqueues the decode of every chunk of the plan on `hip_stream` (a hipStream_t, NULL = default
  * stream). Asynchronous; allocates nothing. Replaces the scheme.decompress(...) call inside
