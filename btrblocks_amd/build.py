@@ -3,6 +3,7 @@
 `python -m btrblocks_amd.build` compiles in-tree:
   btrblocks_amd/libbtrblocks_amd.so   the product: C ABI + HIP kernels + CPU compressor
   oracle/_build/libbtr_oracle.so      test infrastructure: CPU restatement of the decoder
+  examples/compression                round trip through the C++ interface (include/btrblocks_amd.hpp)
 hipcc cross-compiles for gfx950 without a GPU present.
 """
 import os
@@ -66,11 +67,29 @@ def build_oracle(force=False):
     return ORACLE_LIB
 
 
+EXAMPLE_SRC = os.path.join(ROOT, "examples", "compression.cpp")
+EXAMPLE_BIN = os.path.join(ROOT, "examples", "compression")
+
+
+def build_example(force=False):
+    """The C++ example, linked against the in-tree library (found at run time next to the package)."""
+    srcs = [EXAMPLE_SRC, os.path.join(ROOT, "include", "btrblocks_amd.hpp"), os.path.join(ROOT, "include", "btrblocks_amd.h")]
+    if not force and _newer(EXAMPLE_BIN, srcs + [LIB]):
+        return EXAMPLE_BIN
+    subprocess.check_call([
+        "g++", "-std=c++17", "-O2", "-Wall", "-I", os.path.join(ROOT, "include"), EXAMPLE_SRC, "-o", EXAMPLE_BIN,
+        "-L", os.path.dirname(LIB), "-lbtrblocks_amd", "-Wl,-rpath,$ORIGIN/../btrblocks_amd",
+        "-L", "/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib", "-lamdhip64",
+    ])
+    return EXAMPLE_BIN
+
+
 def main():
     force = "--force" in sys.argv
     verbose = "--verbose" in sys.argv
     print(build_library(force, verbose))
     print(build_oracle(force))
+    print(build_example(force))
 
 
 if __name__ == "__main__":

@@ -1,0 +1,61 @@
+// Round trip of a two-column relation through the C++ interface: compress on the CPU, decode on
+// the GPU, compare. Follows the flow of the reference's tools/examples/compression.cpp:56-117
+// (relation -> ranges -> chunk -> Datablock::compress -> Datablock::decompress -> compare).
+//   usage: compression [rows] [scheme spec]
+#include <cstdio>
+#include <cstdlib>
+#include <iostream>
+#include <random>
+
+#include "btrblocks_amd.hpp"
+
+using namespace btrblocks_amd;
+
+// `unique` distinct values in runs of up to `runlength`
+template <typename T>
+static std::vector<T> generateData(size_t size, size_t unique, size_t runlength, int seed) {
+  std::vector<T> data(size);
+  std::mt19937 gen(seed);
+  for (size_t i = 0; i < size;) {
+    const T v = static_cast<T>(gen() % unique) / (sizeof(T) == 8 ? 100.0 : 1);
+    const size_t run = 1 + gen() % runlength;
+    for (size_t j = 0; j < run && i < size; j++, i++) data[i] = v;
+  }
+  return data;
+}
+
+int main(int argc, char** argv) {
+  const size_t size = argc > 1 ? strtoull(argv[1], nullptr, 10) : 640000;
+  const std::string spec = argc > 2 ? argv[2] : "auto";
+  try {
+    Relation to_compress;
+    to_compress.addColumn({"ints", generateData<int32_t>(size, 1 << 12, 40, 42)});
+    to_compress.addColumn({"dbls", generateData<double>(size, 1 << 10, 20, 69)});
+
+    // one block per 65536 rows, as the reference's tools do with Relation::getRanges
+    const std::vector<Range> ranges = to_compress.getRanges(SplitStrategy::SEQUENTIAL, 65536);
+    Datablock compressor(to_compress, 0, spec);
+    size_t compressed = 0, raw = 0;
+    bool check = true;
+    for (size_t chunk_i = 0; chunk_i < ranges.size(); chunk_i++) {
+      Chunk input = to_compress.getChunk(ranges, chunk_i);
+      BytesArray output;
+      const OutputBlockStats stats = compressor.compress(input, output);
+      compressed += stats.total_data_size;
+      raw += stats.total_uncompressed;
+      Chunk decompressed = compressor.decompress(output);
+      check = check && (input == decompressed);
+    }
+    std::cout << "Stats:" << std::endl
+              << "- input size " << raw << std::endl
+              << "- output size " << compressed << std::endl
+              << "- compression ratio " << (compressed ? (double)raw / compressed : 0) << std::endl
+              << "- blocks " << ranges.size() << std::endl;
+    std::cout << (check ? "decompressed data matches original data" : "decompressed data does not match original data")
+              << std::endl;
+    return check ? 0 : 1;
+  } catch (const Generic_Exception& e) {
+    std::cerr << "btrblocks_amd error " << e.status << ": " << e.what() << std::endl;
+    return 2;
+  }
+}

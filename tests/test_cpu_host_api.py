@@ -82,3 +82,17 @@ def test_auto_picker_is_deterministic_and_sensible():
     assert B.describe(B.compress_chunk(np.full(100, 3, np.int32), None, "auto")) == "ONE_VALUE"
     rng = np.random.default_rng(0)
     assert B.describe(B.compress_chunk(rng.uniform(-1e6, 1e6, 65536), None, "auto")) == "UNCOMPRESSED"
+
+
+def test_cpp_example_fails_loudly_without_gpu():
+    """The C++ interface example (include/btrblocks_amd.hpp) is built in-tree; without a HIP device
+    it must stop with the device error instead of decoding on the CPU."""
+    import subprocess
+    import torch
+    exe = os.path.join(ROOT, "examples", "compression")
+    assert os.path.exists(exe), "run python -m btrblocks_amd.build"
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by the gpu test")
+    r = subprocess.run([exe, "1000"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 2
+    assert "no HIP device" in r.stderr

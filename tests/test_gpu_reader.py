@@ -1,5 +1,7 @@
 """GPU: the BtrReader / Datablock mirrors, device-resident whole-column decode and malformed
 stream detection, all through the C ABI."""
+import os
+
 import numpy as np
 import pytest
 
@@ -111,3 +113,15 @@ def test_full_size_column_properties(gpu_ctx):
     for i in (0, 1234, 4095):
         o, n = r.chunks[i]
         np.testing.assert_array_equal(r.readColumn(i), pyoracle.decode_chunk(image[o:o + n]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("spec", ["auto", "rle", "dict"])
+def test_cpp_interface_round_trip(spec):
+    """examples/compression: Relation -> Datablock::compress -> Datablock::decompress through
+    include/btrblocks_amd.hpp, ten 65536-row blocks of an integer and a double column."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "compression")
+    r = subprocess.run([exe, "640000", spec], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "decompressed data matches original data" in r.stdout
