@@ -91,6 +91,8 @@ constexpr uint32_t DEC_EXCEPTION_CODE = 23;
 constexpr uint32_t DEC_INDEX_MASK = 0x1F;
 constexpr uint32_t DEC_GROUP_ROWS = 4;  // rows per entry of the CPU-only exception map (Pseudodecimal.hpp:9)
 
+// FastPFor CompositeCodec<SIMDFastPFor<8>, VariableByte> geometry
+constexpr uint32_t PFOR_BLOCK = 256, PFOR_PAGE = 65536;
 // FastPFor CompositeCodec<FastBinaryPacking<32>, VariableByte> geometry
 constexpr uint32_t FBP_MINIBLOCK = 32;      // values per miniblock
 constexpr uint32_t FBP_GROUP = 128;         // values per header word (4 miniblocks)

@@ -113,6 +113,7 @@ struct Ctx {
   u32 steps_off, pipes_off, seqs_off;  // LDS byte offsets of the program tables
   u32 table_base;                      // LDS byte offset of table space
   u32 red_off;                         // 64 bytes of LDS for block-wide reductions
+  u32 consts_off;                      // LDS byte offset of the program's constant words
   u32 debug;                           // WorkItem::debug_flags
 };
 
@@ -1665,6 +1666,180 @@ __device__ __forceinline__ void bitmap_starts(const Ctx& c, const Step& s) {
   if (bad) raise(c, ST_RLE_COUNTS);
 }
 
+// ---- step: SIMDFastPFor<8> + VariableByte stream -> sequence (integer/PBP.cpp:37-49, 92-109) --------
+// One value of a SIMD pack of 128 at width b: value i lives in lane i % 4 at bit (i / 4) * b of
+// that lane's stream; word k of lane L is word 4k + L of the pack.
+__device__ __forceinline__ u32 simd_pack_get(__amdgpu_buffer_rsrc_t rsrc, u32 word0, u32 b, u32 i) {
+  const u32 bit = (i >> 2) * b;
+  const u32 w = word0 + 4 * (bit >> 5) + (i & 3);
+  const u32 lo = __builtin_amdgcn_raw_buffer_load_b32(rsrc, w * 4, 0, 0);
+  const u32 hi = __builtin_amdgcn_raw_buffer_load_b32(rsrc, (w + 4) * 4, 0, 0);
+  const u32 x = __builtin_amdgcn_alignbit(hi, lo, bit);
+  return b >= 32 ? x : (x & ((1u << b) - 1u));
+}
+
+// VariableByte tail of up to 255 values (7 bits per byte, low group first, a set top bit ends a
+// value): bytes are staged in LDS, every thread owns five of them, a block-wide scan of the
+// terminator counts gives each value its index.
+__device__ __forceinline__ void vbyte_tail_decode(const Ctx& c, __amdgpu_buffer_rsrc_t rsrc, u32 first_word, u32 W,
+                                                  u32 stage_off, const Tab& out, u32 out_first, u32 expect) {
+  const u32 tid = threadIdx.x;
+  const u32 words = W > first_word ? (W - first_word < 320 ? W - first_word : 320) : 0;
+  for (u32 w = tid; w < 320; w += kBlockThreads)
+    lds_st32(stage_off + 4 * w, w < words ? __builtin_amdgcn_raw_buffer_load_b32(rsrc, (first_word + w) * 4, 0, 0) : 0u);
+  __syncthreads();
+  const u32 nbytes = words * 4;
+  u32 cnt = 0;
+  for (u32 j = 5 * tid; j < 5 * tid + 5 && j < nbytes; j++) cnt += lds_raw[stage_off + j] >> 7;
+  u32 total;
+  u32 idx = block_exclusive_scan(c, cnt, &total);
+  for (u32 j = 5 * tid; j < 5 * tid + 5 && j < nbytes; j++) {
+    if (!(lds_raw[stage_off + j] & 128)) continue;
+    u32 start = j;  // first byte of the value that ends at j: behind the previous terminator
+    while (start > 0 && j - start < 4 && !(lds_raw[stage_off + start - 1] & 128)) start--;
+    u32 v = 0;
+    for (u32 q = start; q <= j; q++) v += (u32)(lds_raw[stage_off + q] & 127) << (7 * (q - start));
+    if (idx < expect) tab_st32(out, out_first + idx, v);
+    idx++;
+  }
+  if (total != expect && tid == 0) raise(c, ST_BP_TAIL);
+  __syncthreads();
+}
+
+__device__ __forceinline__ void pfor_decode(const Ctx& c, const Step& s) {
+  const u32 tid = threadIdx.x, lane = tid & 63, wave = uniform(tid >> 6);
+  const u8* base = c.src + uniform(s.a[0]);
+  const u32 W = uniform(s.a[1]);
+  const u32 desc0 = c.consts_off + 4 * uniform(s.a[2]);
+  const u32 pages = uniform(s.a[3]) & 0x7FFFFFFFu;
+  const bool delta = (uniform(s.a[3]) >> 31) != 0;
+  const Tab out = resolve_tab(c, uniform(s.a[4]));
+  const u32 work = seq_lds(c, uniform(s.a[5]));
+  const u32 table_off = work, stage_off = work + 4096 + 1024 * wave, tail_off = work + 8192;
+  const u32 n = out.count;
+  const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(base, W * 4);
+  u32 bad = 0;
+  for (u32 p = 0; p < pages; p++) {
+    const u32 d = desc0 + 4 * kPforPageWords * p;
+    const u32 first = uniform(lds32(d)), len = uniform(lds32(d + 4)), data_word = uniform(lds32(d + 8)),
+              bytes_off = uniform(lds32(d + 12)), bytes_size = uniform(lds32(d + 16));
+    const u32 blocks = len / btrfmt::PFOR_BLOCK;
+    // 1. the byte container is a chain of variable-length records {b, exception count, [max bits,
+    //    positions...]}: one lane follows it and notes {b, count, exception width}, the offset of
+    //    the position bytes and the first word of the block's packs
+    if (tid == 0) {
+      u32 o = 0, dw = data_word;
+      for (u32 r = 0; r < blocks; r++) {
+        u32 b = 0, cex = 0, k = 0;
+        if (o + 2 <= bytes_size) {
+          b = base[bytes_off + o];
+          cex = base[bytes_off + o + 1];
+        } else {
+          bad = 1;
+        }
+        o += 2;
+        if (cex) {
+          const u32 maxb = o < bytes_size ? base[bytes_off + o] : 0u;
+          if (maxb <= b || maxb > 32) bad = 1;
+          k = maxb > b ? maxb - b : 1;
+          o += 1;
+        }
+        if (b > 32) {
+          bad = 1;
+          b = 32;
+        }
+        lds_st32(table_off + 16 * r, b | (cex << 8) | (k << 16));
+        lds_st32(table_off + 16 * r + 4, bytes_off + o);
+        lds_st32(table_off + 16 * r + 12, dw);
+        o += cex;
+        dw += 8 * b;
+      }
+      if (o > bytes_size) bad = 1;
+    }
+    __syncthreads();
+    // 2. index of a block's first exception inside its width class: exceptions of the same width
+    //    in the blocks before it
+    for (u32 r = tid; r < blocks; r += kBlockThreads) {
+      const u32 k = lds32(table_off + 16 * r) >> 16;
+      u32 before = 0;
+      for (u32 q = 0; q < r; q++) {
+        const u32 e = lds32(table_off + 16 * q);
+        before += (e >> 16) == k ? (e >> 8) & 0xFF : 0u;
+      }
+      lds_st32(table_off + 16 * r + 8, before);
+    }
+    __syncthreads();
+    // 3. a wave per block: unpack 256 values into its staging area, patch the exceptions in, store
+    for (u32 r = wave; r < blocks; r += kBlockThreads / 64) {
+      const u32 e = uniform(lds32(table_off + 16 * r)), pos_off = uniform(lds32(table_off + 16 * r + 4)),
+                ex0 = uniform(lds32(table_off + 16 * r + 8)), dw = uniform(lds32(table_off + 16 * r + 12));
+      const u32 b = e & 0xFF, cex = (e >> 8) & 0xFF, k = e >> 16;
+#pragma unroll
+      for (u32 q = 0; q < 4; q++) {
+        const u32 i = lane + 64 * q;
+        lds_st32(stage_off + 4 * i, simd_pack_get(rsrc, dw + (i >> 7) * 4 * b, b, i & 127));
+      }
+      // other lanes patch this lane's staged values: the wave's LDS accesses are served in program
+      // order, the compiler must keep that order (and not forward the staged value in a register)
+      __builtin_amdgcn_wave_barrier();
+      asm volatile("" ::: "memory");
+      if (cex) {
+        const u32 cls_word = k >= 2 ? uniform(lds32(d + 4 * (5 + k - 2))) : 0u;
+        const u32 cls_size = k >= 2 ? uniform(lds32(d + 4 * (5 + 31 + k - 2))) : 0u;
+        const u32 full = cls_size & ~127u;
+        for (u32 x = lane; x < cex; x += 64) {
+          const u32 pos = base[pos_off + x];
+          u32 v = 1;
+          if (k >= 2) {
+            const u32 q = ex0 + x;
+            if (q >= cls_size) {
+              bad = 1;
+              v = 0;
+            } else if (q < full) {
+              v = simd_pack_get(rsrc, cls_word + (q >> 7) * 4 * k, k, q & 127);
+            } else {
+              const u32 qq = q - full;
+              v = bp_extract(rsrc, cls_word + (full >> 7) * 4 * k + (qq >> 5) * k, k, qq & 31);
+            }
+          }
+          const u32 a = stage_off + 4 * pos;
+          lds_st32(a, lds32(a) | (b < 32 ? v << b : 0u));
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (u32 q = 0; q < 4; q++) {
+        const u32 i = lane + 64 * q;
+        tab_st32(out, first + r * btrfmt::PFOR_BLOCK + i, lds32(stage_off + 4 * i));
+      }
+    }
+    __syncthreads();
+  }
+  if (bad) raise(c, ST_BP_HEADER);
+  const u32 rounded = n / btrfmt::PFOR_BLOCK * btrfmt::PFOR_BLOCK;
+  if (n > rounded) {
+    const u32 tail_word = uniform(lds32(desc0 + 4 * kPforPageWords * pages));
+    vbyte_tail_decode(c, rsrc, tail_word, W, tail_off, out, rounded, n - rounded);
+  }
+  if (delta && n > 0) {
+    // PFOR_DELTA: inclusive wrapping prefix sum, 256-value tiles with a running carry
+    if (out.loc != LOC_LDS) {
+      __threadfence_block();
+      __syncthreads();
+    }
+    u32 carry = 0;
+    for (u32 t0 = 0; t0 < n; t0 += kBlockThreads) {
+      const u32 i = t0 + tid;
+      const u32 v = i < n ? tab_ld32(out, i) : 0u;
+      u32 total;
+      const u32 ex = block_exclusive_scan(c, v, &total);
+      if (i < n) tab_st32(out, i, carry + ex + v);
+      carry += total;
+    }
+  }
+}
+
 // bit i = (pipe[i] == value); each wave writes the 64-bit ballot of its 64 consecutive rows.
 // A bare bit-packed pipe is scanned a 128-value group per wave, two groups (four loads) in flight.
 template <u32 THREADS = kBlockThreads>
@@ -1776,6 +1951,7 @@ __device__ __forceinline__ ProgramHeader load_program(const WorkItem& it, u32 it
   c.seqs_off = c.pipes_off + hdr.n_pipes * sizeof(Pipe);
   c.table_base = hdr.table_base;
   c.red_off = hdr.table_base - 64;
+  c.consts_off = BASE + uniform(hdr.consts_off);
   c.debug = it.debug_flags;
   return hdr;
 }
@@ -1865,6 +2041,7 @@ __device__ __forceinline__ void decode_block(const WorkItem* __restrict__ items,
       case S_BITMAP_EQ: bitmap_eq(c, st); break;
       case S_BITMAP_RANK: bitmap_rank(c, st); break;
       case S_NULLMAP: write_nullmap(c, st); break;
+      case S_PFOR_DECODE: pfor_decode(c, st); break;
       default: break;
     }
     __syncthreads();

@@ -72,8 +72,114 @@ size_t fbp_encode(const uint32_t* in, size_t n, std::vector<uint32_t>& out) {
   return out.size() - start;
 }
 
-size_t pfor_encode(const uint32_t*, size_t, std::vector<uint32_t>&) {
-  throw std::runtime_error("PFOR (SIMDFastPFor) encoding is not available in this build");
+// ------------------------------------------------------------------------------------------
+// SIMDFastPFor<8> (restated from FastPFor's simdfastpfor.h / simdbitpacking):
+//   word 0            number of values coded by this codec (a multiple of 256)
+//   per page of at most 65536 values:
+//     header word     distance in words from the header to the metadata
+//     zero words up to a 16-byte boundary of the absolute address
+//     per 256-value block: two 128-value SIMD packs of b words x 4 lanes each
+//     metadata        u32 byte count; the byte container {b, exception count, [max bits, positions...]}
+//                     per block, zero-padded to a word; u32 bitmap of the exception widths in use
+//                     (bit k-1 for width k = max bits - b >= 2); per width in ascending order: u32
+//                     count, then the values (value >> b) packed at that width - SIMD packs of 128,
+//                     then 32-value horizontal packs, the last one cut to whole used words
+//   A width-1 exception is implied (bit b set), it stores nothing.
+// SIMD pack of 128 values at width b: value i lives in lane i % 4 at bit (i / 4) * b of that
+// lane's stream; word k of lane L is word 4k + L of the pack.
+namespace {
+
+void simd_pack128(const uint32_t* in, uint32_t b, std::vector<uint32_t>& out) {
+  const size_t base = out.size();
+  out.resize(base + 4 * (size_t)b, 0);
+  if (b == 0) return;
+  for (uint32_t i = 0; i < 128; i++) {
+    const uint32_t lane = i & 3, bit = (i >> 2) * b, k = bit >> 5, sh = bit & 31;
+    const uint64_t v = (uint64_t)(b == 32 ? in[i] : (in[i] & ((1u << b) - 1))) << sh;
+    out[base + 4 * k + lane] |= (uint32_t)v;
+    if (sh + b > 32) out[base + 4 * (k + 1) + lane] |= (uint32_t)(v >> 32);
+  }
+}
+
+void pack_exceptions(const std::vector<uint32_t>& src, uint32_t bit, std::vector<uint32_t>& out) {
+  const size_t size = src.size();
+  out.push_back((uint32_t)size);
+  if (size == 0) return;
+  std::vector<uint32_t> padded(src);
+  padded.resize((size + 31) / 32 * 32, 0);
+  size_t j = 0;
+  for (; j + 128 <= size; j += 128) simd_pack128(padded.data() + j, bit, out);
+  for (; j < size; j += 32) pack_miniblock(padded.data() + j, bit, out);
+  out.resize(out.size() - (j - size) * bit / 32);  // whole words the padding alone would occupy
+}
+
+// Width b, exception count and largest width of one block: FastPFor's cost model (8 bits per
+// exception position, the exception's extra bits, 8 bits for the max-bits byte).
+void best_b(const uint32_t* in, uint32_t& bestb, uint32_t& bestc, uint32_t& maxb) {
+  uint32_t freqs[33] = {0};
+  for (uint32_t k = 0; k < btrfmt::PFOR_BLOCK; k++) freqs[bits_needed(in[k])]++;
+  bestb = 32;
+  while (bestb > 0 && freqs[bestb] == 0) bestb--;
+  maxb = bestb;
+  uint32_t bestcost = bestb * btrfmt::PFOR_BLOCK, cexcept = 0;
+  bestc = 0;
+  for (uint32_t b = bestb; b-- > 0;) {
+    cexcept += freqs[b + 1];
+    if (cexcept > 255) break;  // the count is stored in one byte
+    uint32_t cost = cexcept * 8 + cexcept * (maxb - b) + b * btrfmt::PFOR_BLOCK + 8;
+    if (maxb - b == 1) cost -= cexcept;
+    if (cost < bestcost) {
+      bestcost = cost;
+      bestb = b;
+      bestc = cexcept;
+    }
+  }
+}
+
+}  // namespace
+
+size_t pfor_encode(const uint32_t* in, size_t n, std::vector<uint32_t>& out, size_t first_word_mod4) {
+  const size_t start = out.size();
+  const size_t rounded = n / btrfmt::PFOR_BLOCK * btrfmt::PFOR_BLOCK;
+  out.push_back((uint32_t)rounded);
+  for (size_t page = 0; page < rounded; page += btrfmt::PFOR_PAGE) {
+    const size_t len = std::min<size_t>(btrfmt::PFOR_PAGE, rounded - page);
+    const size_t header = out.size();
+    out.push_back(0);
+    while ((first_word_mod4 + (out.size() - start)) % 4) out.push_back(0);  // 16-byte boundary
+    std::vector<uint8_t> bytes;
+    std::vector<uint32_t> classes[33];
+    for (size_t blk = 0; blk < len; blk += btrfmt::PFOR_BLOCK) {
+      const uint32_t* v = in + page + blk;
+      uint32_t b, cexcept, maxb;
+      best_b(v, b, cexcept, maxb);
+      bytes.push_back((uint8_t)b);
+      bytes.push_back((uint8_t)cexcept);
+      if (cexcept > 0) {
+        bytes.push_back((uint8_t)maxb);
+        for (uint32_t k = 0; k < btrfmt::PFOR_BLOCK; k++)
+          if (b < 32 && (v[k] >> b) != 0) {
+            classes[maxb - b].push_back(v[k] >> b);
+            bytes.push_back((uint8_t)k);
+          }
+      }
+      simd_pack128(v, b, out);
+      simd_pack128(v + 128, b, out);
+    }
+    out[header] = (uint32_t)(out.size() - header);
+    out.push_back((uint32_t)bytes.size());
+    const size_t bw = out.size();
+    out.resize(bw + (bytes.size() + 3) / 4, 0);
+    if (!bytes.empty()) memcpy(out.data() + bw, bytes.data(), bytes.size());
+    uint32_t bitmap = 0;
+    for (uint32_t k = 2; k <= 32; k++)
+      if (!classes[k].empty()) bitmap |= 1u << (k - 1);
+    out.push_back(bitmap);
+    for (uint32_t k = 2; k <= 32; k++)
+      if (!classes[k].empty()) pack_exceptions(classes[k], k, out);
+  }
+  if (rounded < n) vbyte_encode(in + rounded, n - rounded, out);
+  return out.size() - start;
 }
 
 // ------------------------------------------------------------------------------------------

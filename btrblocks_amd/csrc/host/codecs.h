@@ -20,8 +20,10 @@ namespace btrhost {
 // Appends 32-bit words to `out`; returns the number of words appended.
 size_t fbp_encode(const uint32_t* in, size_t n, std::vector<uint32_t>& out);
 
-// SIMDFastPFor<8> over the first n/256*256 values, VariableByte over the rest.
-size_t pfor_encode(const uint32_t* in, size_t n, std::vector<uint32_t>& out);
+// SIMDFastPFor<8> over the first n/256*256 values, VariableByte over the rest. The codec pads to
+// 16-byte boundaries of the absolute address: `first_word_mod4` is (address of the first word
+// appended / 4) % 4 at the place the stream will finally live.
+size_t pfor_encode(const uint32_t* in, size_t n, std::vector<uint32_t>& out, size_t first_word_mod4);
 
 // Serialize a sorted, duplicate-free list of row ids the way roaring_bitmap_serialize does
 // after runOptimize(). Appends bytes to `out`; returns the number of bytes appended.

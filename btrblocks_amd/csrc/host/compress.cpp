@@ -242,7 +242,7 @@ void emit_fastpfor(Writer& w, const uint32_t* vals, size_t n, bool pfor) {
   w.reserve(pad);
   std::vector<uint32_t> words;
   if (pfor)
-    pfor_encode(vals, n, words);
+    pfor_encode(vals, n, words, ((w.pos() - w.origin) / 4) % 4);
   else
     fbp_encode(vals, n, words);
   w.put(words.data(), words.size() * 4);
@@ -499,7 +499,7 @@ template <typename T>
 uint8_t pick_scheme(const Ctx& cx, const T* src, const uint8_t* nm, uint32_t n, int level,
                     const Stats<T>& st) {
   constexpr bool is_double = sizeof(T) == 8;
-  static const uint8_t kInt[] = {I_DICT, I_RLE, I_BP, I_BP};
+  static const uint8_t kInt[] = {I_DICT, I_RLE, I_PFOR, I_BP};
   static const uint8_t kDbl[] = {D_DICT, D_RLE, D_FREQUENCY, D_PSEUDODECIMAL};
   const uint8_t* cand = is_double ? kDbl : kInt;
   std::vector<T> sv;
@@ -572,7 +572,7 @@ uint8_t compress_int(Writer& w, const Ctx& cx, const int32_t* src, const uint8_t
         const size_t pad = w.pad_to(4);
         w.reserve(pad);
         std::vector<uint32_t> words;
-        pfor_encode(d.data(), n, words);
+        pfor_encode(d.data(), n, words, ((w.pos() - w.origin) / 4) % 4);
         w.put(words.data(), words.size() * 4);
         wr32(w.at(hdr + BP_WORDS), (uint32_t)words.size());
         *w.at(hdr + BP_PADDING) = (uint8_t)pad;

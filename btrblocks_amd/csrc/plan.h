@@ -84,10 +84,19 @@ enum : uint8_t {
   S_BITMAP_RANK = 6,    // a1 seq bitmap, a2 seq rank, a3 bit count, a4 expected popcount (or NONE),
                         // a5 status bit to raise on a mismatch
   S_NULLMAP = 7,        // a0 nullmap type, a1 seq bitmap (REGULAR/FLIPPED, else NONE), a3 row count
+  S_PFOR_DECODE = 9,    // see below
   S_STREAM_ROOT = 8,    // a0 pipe id (B_BP or B_PSEUDO base), a1 dst seq id, a2 seq id of the powers-of-ten
                         // table (B_PSEUDO), a3 seq id of the walker's jump tables: root step that stages the payload(s) through LDS rings,
                         // indexing and unpacking them batch by batch
 };
+// S_PFOR_DECODE = 9: decodes a SIMDFastPFor<8>+VariableByte stream into a sequence.
+//   a0 payload byte offset in the chunk (4-byte aligned device address), a1 stored word count,
+//   a2 word index (in the program's constant words) of the page descriptors followed by one word
+//   "first word of the VariableByte tail", a3 page count | (1u << 31 for PFOR_DELTA: prefix sum
+//   afterwards), a4 dst seq id, a5 seq id of kPforWorkBytes of LDS
+// Page descriptor (kPforPageWords words): first value, value count, first word of the packed
+//   blocks, byte offset and size of the byte container, then for every exception width k = 2..32
+//   the first word of its packed values and, after all of those, their counts.
 // Element kinds of S_BITMAP_SET: the four member encodings of CRoaring's native serialization.
 enum : uint32_t { SET_ARRAY32 = 0, SET_ARRAY16 = 1, SET_BITSET = 2, SET_RUNS = 3 };
 struct Step {
@@ -103,9 +112,10 @@ struct ProgramHeader {
   uint32_t n_seqs;
   uint32_t table_base;  // absolute LDS byte offset where table space starts (after the program copy
                         // and 64 bytes of reduction scratch)
-  uint32_t pad[3];
+  uint32_t consts_off;  // byte offset of the constant words from the start of the program
+  uint32_t pad[2];
 };
-// A program is laid out as: ProgramHeader | Step[n_steps] | Pipe[n_pipes] | Seq[n_seqs]
+// A program is laid out as: ProgramHeader | Step[n_steps] | Pipe[n_pipes] | Seq[n_seqs] | u32 consts[]
 
 struct WorkItem {
   uint64_t src;          // device address of the chunk envelope / block column payload base
@@ -154,6 +164,11 @@ constexpr uint32_t kStreamRingBytes = 16 * 1024;  // LDS ring of the streamed ro
 constexpr uint32_t kStreamProgBase = kStreamRingBytes + 16;
 // LDS scratch of one header-chain walker: a table of (1024 + 256) 16-bit jump pointers.
 constexpr uint32_t kWalkScratchBytes = (1024 + 256) * 2;
+// SIMDFastPFor page descriptor size and the LDS work area of S_PFOR_DECODE: a 16-byte entry per
+// 256-value block of a page (256 blocks), 1 KiB of staging per wave of the generic kernels, and
+// up to 1280 bytes of VariableByte tail (255 values of at most 5 bytes).
+constexpr uint32_t kPforPageWords = 5 + 31 + 31;
+constexpr uint32_t kPforWorkBytes = 4096 + 4096 + 1280;
 // Streams with more groups than this get jump tables; shorter ones are walked without.
 constexpr uint32_t kWalkScratchMinGroups = 64;
 constexpr uint32_t kLdsCapBytes = 160 * 1024;  // all of a gfx950 CU's LDS; typical chunks need 5-40 KiB

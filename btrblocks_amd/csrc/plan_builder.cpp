@@ -36,6 +36,8 @@ struct Builder {
   std::vector<Step> bp_steps, steps;
   std::vector<Pipe> pipes;
   std::vector<Seq> seqs;
+  std::vector<uint32_t> consts;        // constant words appended to the program
+  std::vector<uint32_t> pfor_outputs;  // sequences filled by S_PFOR_DECODE steps
   uint64_t needed = 0;
   uint32_t max_depth = 0;
 
@@ -221,6 +223,81 @@ struct Builder {
     return p;
   }
 
+  // SIMDFastPFor<8> + VariableByte stream (integer/PBP.cpp:37-49, 92-109). The page structure
+  // (a handful of words per 65536 values) is parsed here; the per-block byte container and the
+  // packed data are read on the device. The stream is always decoded into a table.
+  uint32_t pfor_node(size_t off, uint32_t n, bool delta, std::string& desc) {
+    const uint32_t words = w(off + BP_WORDS);
+    const uint32_t padding = b(off + BP_PADDING);
+    const size_t payload = off + BP_DATA + padding;
+    need(payload, (size_t)words * 4, "PFOR payload");
+    if ((cs.dev_addr + payload) % 4 != 0)
+      throw PlanError(ST_MISALIGNED,
+                      "PFOR payload is not 4-byte aligned at its device address; place the compressed "
+                      "bytes at the alignment they were compressed at (16 bytes)");
+    const uint32_t misalign = (uint32_t)(((cs.dev_addr + payload) / 4) % 4);
+    auto pw = [&](size_t word) {
+      if (word >= words) corrupt("PFOR metadata runs past the payload");
+      return w(payload + word * 4);
+    };
+    const uint32_t consts_at = (uint32_t)consts.size();
+    uint32_t pages = 0;
+    size_t in = 0;
+    if (n > 0) {
+      if (words == 0) corrupt("empty PFOR payload");
+      const uint32_t rounded = pw(0);
+      if (rounded != n / PFOR_BLOCK * PFOR_BLOCK) corrupt("PFOR length word does not match the value count");
+      in = 1;
+      for (uint32_t done = 0; done < rounded;) {
+        const uint32_t len = std::min<uint32_t>(PFOR_PAGE, rounded - done);
+        const size_t header = in;
+        const size_t meta = header + pw(header);
+        const uint32_t bytesize = pw(meta);
+        if (bytesize > (uint64_t)(words - meta) * 4) corrupt("PFOR byte container runs past the payload");
+        size_t ex = meta + 1 + (bytesize + 3) / 4;
+        const uint32_t bitmap = pw(ex);
+        ex++;
+        size_t data = header + 1;
+        while ((misalign + data) % 4) data++;
+        uint32_t cls_word[33] = {0}, cls_size[33] = {0};
+        for (uint32_t k = 2; k <= 32; k++) {
+          if (!((bitmap >> (k - 1)) & 1)) continue;
+          const uint32_t size = pw(ex);
+          ex++;
+          cls_word[k] = (uint32_t)ex;
+          cls_size[k] = size;
+          const uint64_t full = size / 128, rest = (size % 128 + 31) / 32;
+          uint64_t used = full * 4 * k + rest * k;
+          used -= (uint64_t)((full * 128 + rest * 32) - size) * k / 32;
+          if (ex + used > words) corrupt("PFOR exception values run past the payload");
+          ex += used;
+        }
+        consts.push_back(done);
+        consts.push_back(len);
+        consts.push_back((uint32_t)data);
+        consts.push_back((uint32_t)((meta + 1) * 4));
+        consts.push_back(bytesize);
+        for (uint32_t k = 2; k <= 32; k++) consts.push_back(cls_word[k]);
+        for (uint32_t k = 2; k <= 32; k++) consts.push_back(cls_size[k]);
+        if (data > meta) corrupt("PFOR packed blocks overlap the metadata");
+        pages++;
+        in = ex;
+        done += len;
+      }
+      if (in > words) corrupt("PFOR pages run past the payload");
+    }
+    consts.push_back((uint32_t)in);  // first word of the VariableByte tail
+    const uint32_t out = add_seq(LOC_LDS, 0, n, 4);
+    const uint32_t work = add_seq(LOC_LDS, 0, kPforWorkBytes / 16, 16, true);
+    add_step(S_PFOR_DECODE, (uint32_t)payload, words, consts_at, pages | (delta ? 1u << 31 : 0u), out, work);
+    pfor_outputs.push_back(out);
+    needed += BP_DATA + (uint64_t)words * 4;
+    desc = delta ? "PFOR_DELTA" : "PFOR";
+    const uint32_t p = add_pipe(B_SEQ, false, n);
+    pipes[p].a[0] = out;
+    return p;
+  }
+
   template <typename CodeT>
   uint32_t fixed_dict_node(size_t off, uint32_t n, bool is_double, std::string& desc) {
     const uint32_t esz = is_double ? 8 : 4;
@@ -365,9 +442,8 @@ struct Builder {
       }
       case I_DICTIONARY_8: return fixed_dict_node<uint8_t>(off, n, false, desc);
       case I_DICTIONARY_16: return fixed_dict_node<uint16_t>(off, n, false, desc);
-      case I_PFOR:
-      case I_PFOR_DELTA:
-        throw PlanError(ST_UNSUPPORTED, "PFOR (SIMDFastPFor) streams are not supported yet");
+      case I_PFOR: return pfor_node(off, n, false, desc);
+      case I_PFOR_DELTA: return pfor_node(off, n, true, desc);
       case I_TRUNCATION_8:
       case I_TRUNCATION_16:
         // The reference cannot decode these either (integer/Truncation.hpp:88-97).
@@ -465,7 +541,7 @@ uint32_t align_up(uint32_t v, uint32_t a) { return (v + a - 1) / a * a; }
 void build_program(const ColumnSource& src, BuiltProgram& out) {
   if (src.column_type != COL_INTEGER && src.column_type != COL_DOUBLE)
     throw PlanError(ST_UNSUPPORTED, "only integer and double columns are decoded on the GPU");
-  Builder bld{src, {}, {}, {}, {}, 0, 0};
+  Builder bld{src, {}, {}, {}, {}, {}, {}, 0, 0};
   const uint32_t n = src.tuple_count;
   std::string desc;
   uint32_t root;
@@ -514,7 +590,16 @@ void build_program(const ColumnSource& src, BuiltProgram& out) {
       prog_base = kStreamProgBase;
       kernel = KERNEL_STREAM_PSEUDO;
     } else {
-      bld.add_step(S_MATERIALIZE, root, dst);
+      // a root that is just a decoded PFOR table: decode straight into the column
+      bool direct = false;
+      if (rp.base == B_SEQ && rp.n_post == 0)
+        for (Step& st : bld.steps)
+          if (st.kind == S_PFOR_DECODE && st.a[4] == rp.a[0]) {
+            bld.seqs[st.a[4]].count = 0;
+            st.a[4] = dst;
+            direct = true;
+          }
+      if (!direct) bld.add_step(S_MATERIALIZE, root, dst);
     }
   }
   // LDS scratch for the header-chain walkers: index step s runs on wave s % 4, so four slots
@@ -544,8 +629,8 @@ void build_program(const ColumnSource& src, BuiltProgram& out) {
   // ---- lay the program out, then place tables: mandatory LDS tables first, optional ones in
   // LDS while the soft cap holds, the rest in the chunk's scratch slice.
   const size_t n_steps = bld.bp_steps.size() + bld.steps.size();
-  const size_t prog_bytes = sizeof(ProgramHeader) + n_steps * sizeof(Step) +
-                            bld.pipes.size() * sizeof(Pipe) + bld.seqs.size() * sizeof(Seq);
+  const size_t prog_bytes = sizeof(ProgramHeader) + n_steps * sizeof(Step) + bld.pipes.size() * sizeof(Pipe) +
+                            bld.seqs.size() * sizeof(Seq) + bld.consts.size() * 4;
   const uint32_t table_base = prog_base + align_up((uint32_t)prog_bytes, 16) + 64;  // + reduction scratch
   uint64_t lds = 0, scratch = 0;
   for (auto& s : bld.seqs)
@@ -601,8 +686,9 @@ void build_program(const ColumnSource& src, BuiltProgram& out) {
     if (bld.seqs[bld.pipes[root].post[0].arg].loc != LOC_LDS) kernel = KERNEL_STREAM_DICT_GLB;
   }
   const size_t n_steps_final = bld.bp_steps.size() + bld.steps.size();
-  const size_t prog_bytes_final = sizeof(ProgramHeader) + n_steps_final * sizeof(Step) +
-                                  bld.pipes.size() * sizeof(Pipe) + bld.seqs.size() * sizeof(Seq);
+  const size_t consts_off = sizeof(ProgramHeader) + n_steps_final * sizeof(Step) + bld.pipes.size() * sizeof(Pipe) +
+                            bld.seqs.size() * sizeof(Seq);
+  const size_t prog_bytes_final = consts_off + bld.consts.size() * 4;
   out.program.assign(prog_bytes_final, 0);
   uint8_t* p = out.program.data();
   ProgramHeader hdr{};
@@ -611,6 +697,7 @@ void build_program(const ColumnSource& src, BuiltProgram& out) {
   hdr.n_pipes = (uint32_t)bld.pipes.size();
   hdr.n_seqs = (uint32_t)bld.seqs.size();
   hdr.table_base = table_base;
+  hdr.consts_off = (uint32_t)consts_off;
   memcpy(p, &hdr, sizeof(hdr));
   p += sizeof(hdr);
   if (!bld.bp_steps.empty()) memcpy(p, bld.bp_steps.data(), bld.bp_steps.size() * sizeof(Step));
@@ -620,6 +707,8 @@ void build_program(const ColumnSource& src, BuiltProgram& out) {
   memcpy(p, bld.pipes.data(), bld.pipes.size() * sizeof(Pipe));
   p += bld.pipes.size() * sizeof(Pipe);
   memcpy(p, bld.seqs.data(), bld.seqs.size() * sizeof(Seq));
+  p += bld.seqs.size() * sizeof(Seq);
+  if (!bld.consts.empty()) memcpy(p, bld.consts.data(), bld.consts.size() * 4);
   out.kernel = kernel;
   out.lds_bytes = table_base + (uint32_t)lds;
   out.scratch_bytes = (uint32_t)scratch;

@@ -45,13 +45,14 @@ struct DecodeError : std::runtime_error {
 struct Span {
   const u8* p;
   size_t n;
+  const u8* origin = nullptr;  // start of the chunk / block: a 16-byte boundary when it was compressed
   const u8* at(size_t off, size_t len) const {
     if (off > n || len > n - off) throw DecodeError("read past the end of the compressed data");
     return p + off;
   }
   Span from(size_t off) const {
     if (off > n) throw DecodeError("offset past the end of the compressed data");
-    return Span{p + off, n - off};
+    return Span{p + off, n - off, origin};
   }
   u8 b(size_t off) const { return *at(off, 1); }
   u16 h(size_t off) const {
@@ -143,6 +144,98 @@ void fbp_decode(const Span& payload, u32 words, u32* out, size_t n) {
   }
   if (pos > words) throw DecodeError("FastBinaryPacking payload overruns its word count");
   const size_t tail = vbyte_decode(payload, pos, words, out + rounded, n - rounded);
+  if (rounded + tail != n) throw DecodeError("FastPFor stream holds the wrong number of values");
+}
+
+// SIMD pack of 128 values at width b (FastPFor simdbitpacking): value i lives in lane i % 4 at
+// bit (i / 4) * b of that lane's stream; word k of lane L is word 4k + L of the pack.
+u32 simd_get(const Span& s, size_t word0, u32 b, u32 i) {
+  if (b == 0) return 0;
+  const u32 lane = i & 3, bit = (i >> 2) * b, k = bit >> 5, sh = bit & 31;
+  u64 v = (u64)s.w((word0 + 4 * (size_t)k + lane) * 4) >> sh;
+  if (sh + b > 32) v |= (u64)s.w((word0 + 4 * (size_t)(k + 1) + lane) * 4) << (32 - sh);
+  return (u32)(b == 32 ? v : (v & ((1ull << b) - 1)));
+}
+
+// CompositeCodec<SIMDFastPFor<8>, VariableByte>::decodeArray (restated from FastPFor's
+// simdfastpfor.h): pages of at most 65536 values, blocks of 256 values packed at width b as two
+// SIMD packs, exceptions (value >> b) grouped by their width max_bits - b and patched back by
+// position. `misalign` = (address of the payload / 4) % 4 when it was compressed: the codec pads
+// to 16-byte boundaries of the absolute address.
+void pfor_decode(const Span& payload, u32 words, u32* out, size_t n, u32 misalign) {
+  if (n == 0) return;
+  if (words == 0) throw DecodeError("empty PFOR payload");
+  payload.at(0, (size_t)words * 4);
+  const u32 rounded = payload.w(0);
+  if (rounded > n || rounded % 256 != 0 || n - rounded >= 256) throw DecodeError("bad PFOR length word");
+  size_t in = 1;
+  for (u32 done = 0; done < rounded;) {
+    const u32 len = std::min<u32>(65536, rounded - done);
+    const size_t header = in;
+    const size_t meta = header + payload.w(header * 4);
+    const u32 bytesize = payload.w(meta * 4);
+    const u8* bytes = payload.at((meta + 1) * 4, bytesize);
+    size_t ex = meta + 1 + (bytesize + 3) / 4;
+    const u32 bitmap = payload.w(ex * 4);
+    ex++;
+    std::vector<u32> classes[33];
+    for (u32 k = 2; k <= 32; k++) {
+      if (!(bitmap >> (k - 1) & 1)) continue;
+      const u32 size = payload.w(ex * 4);
+      ex++;
+      classes[k].resize(size);
+      u32 j = 0;
+      for (; j + 128 <= size; j += 128) {
+        for (u32 i = 0; i < 128; i++) classes[k][j + i] = simd_get(payload, ex, k, i);
+        ex += 4 * k;
+      }
+      for (; j < size; j += 32) {
+        u32 tmp[32];
+        const u32 used = std::min<u32>(32, size - j);
+        // the last pack is cut to the words its used values touch
+        const size_t need = ((size_t)used * k + 31) / 32;
+        payload.at(ex * 4, need * 4);
+        std::vector<u32> padded(k, 0);
+        memcpy(padded.data(), payload.at(ex * 4, need * 4), need * 4);
+        unpack32(Span{(const u8*)padded.data(), (size_t)k * 4, nullptr}, 0, k, tmp);
+        for (u32 i = 0; i < used; i++) classes[k][j + i] = tmp[i];
+        ex += k;
+      }
+      ex -= (size_t)(j - size) * k / 32;
+    }
+    size_t data = header + 1;
+    while ((misalign + data) % 4) data++;
+    size_t bp = 0;
+    size_t next[33] = {0};
+    for (u32 blk = 0; blk < len; blk += 256) {
+      if (bp + 2 > bytesize) throw DecodeError("PFOR byte container too short");
+      const u32 b = bytes[bp++], cexcept = bytes[bp++];
+      if (b > 32) throw DecodeError("PFOR bit width above 32");
+      u32* o = out + done + blk;
+      for (u32 i = 0; i < 256; i++) o[i] = simd_get(payload, data + (i >> 7) * 4 * (size_t)b, b, i & 127);
+      data += 8 * (size_t)b;
+      if (cexcept > 0) {
+        if (bp + 1 + cexcept > bytesize) throw DecodeError("PFOR byte container too short");
+        const u32 maxbits = bytes[bp++];
+        if (maxbits <= b || maxbits > 32) throw DecodeError("bad PFOR exception width");
+        const u32 k = maxbits - b;
+        for (u32 e = 0; e < cexcept; e++) {
+          const u32 pos = bytes[bp++];
+          if (k == 1) {
+            o[pos] |= 1u << b;
+          } else {
+            if (next[k] >= classes[k].size()) throw DecodeError("PFOR exception stream too short");
+            o[pos] |= classes[k][next[k]++] << b;
+          }
+        }
+      }
+    }
+    if (data > meta) throw DecodeError("PFOR packed data overruns the metadata");
+    in = ex;
+    done += len;
+  }
+  if (in > words) throw DecodeError("PFOR payload overruns its word count");
+  const size_t tail = vbyte_decode(payload, in, words, out + rounded, n - rounded);
   if (rounded + tail != n) throw DecodeError("FastPFor stream holds the wrong number of values");
 }
 
@@ -343,9 +436,19 @@ void decode_int(s32* dest, const NullmapView& nm, const Span& src, u32 n, u8 sch
     }
     case 30: decode_fixed_dict<s32, u8>(dest, src, n); return;
     case 31: decode_fixed_dict<s32, u16>(dest, src, n); return;
-    case 4:
-    case 27:
-      throw DecodeError("PFOR streams are not supported by this oracle build");
+    case 4:     // PFOR, integer/PBP.cpp:37-49
+    case 27: {  // PFOR_DELTA, integer/PBP.cpp:92-109: PFOR, then the prefix sum of revertDelta
+      const u32 words = src.w(0);
+      const u32 padding = src.b(4);
+      const Span payload = src.from(5 + padding);
+      if (!payload.origin) throw DecodeError("PFOR needs the chunk origin");
+      const size_t off = (size_t)(payload.p - payload.origin);
+      if (off % 4) throw DecodeError("PFOR payload is not word aligned");
+      pfor_decode(payload, words, (u32*)dest, n, (u32)((off / 4) % 4));
+      if (scheme == 27)
+        for (u32 i = 1; i < n; i++) dest[i] = (s32)((u32)dest[i] + (u32)dest[i - 1]);
+      return;
+    }
     default:
       // Truncation (28/29) is UNREACHABLE in the reference too (integer/Truncation.hpp:88-97).
       throw DecodeError("integer scheme cannot be decoded");
@@ -459,7 +562,7 @@ void decode_nullmap(u8* dest, const Span& src, u8 type, u32 n) {
 // compression/BtrReader.cpp:31-74 (readColumn) over one ColumnChunkMeta chunk
 // (compression/Datablock.hpp:12-21).
 void decode_chunk(const u8* chunk, size_t bytes, void* dst, size_t dst_bytes, u8* nullmap_dst) {
-  const Span s{chunk, bytes};
+  const Span s{chunk, bytes, chunk};
   const u8 scheme = s.b(0), nm_type = s.b(1), col = s.b(2);
   const u32 nm_off = s.w(4), n = s.w(8);
   const Span data = s.from(12);
@@ -509,7 +612,7 @@ int btr_oracle_chunk_info(const uint8_t* chunk, size_t bytes, uint32_t* tuple_co
 int btr_oracle_decode_datablock_column(const uint8_t* block, size_t bytes, uint32_t column,
                                        void* dst, size_t dst_bytes, uint8_t* nullmap_dst) {
   try {
-    const Span s{block, bytes};
+    const Span s{block, bytes, block};
     const u32 n = s.w(0), cols = s.w(8);
     if (column >= cols) throw DecodeError("column index out of range");
     const size_t m = 16 + 16ull * column;

@@ -51,6 +51,26 @@ def cases():
     add("int_depth5_for_chain", synth.int_for(N), "for(for(for(bp)))", max_cascade_depth=5)
     add("int_example_auto", synth.example_runs(65000), "auto")
     add("int_auto_random", _rng(17).integers(0, 100000, N).astype(np.int32), "auto")
+    # PFOR (SIMDFastPFor<8> + VariableByte) and the legacy PFOR_DELTA
+    outliers = _rng(30).integers(0, 1000, N).astype(np.int32)
+    outliers[_rng(31).integers(0, N, N // 50)] = _rng(32).integers(0, 2**31 - 1, N // 50).astype(np.int32)
+    add("int_pfor_outliers", outliers, "pfor")
+    add("int_pfor_kat10_x40", np.tile(KAT10, 40), "pfor")
+    add("int_pfor_zeros", np.zeros(3000, dtype=np.int32), "pfor")
+    w1 = _rng(33).integers(0, 4, 4096).astype(np.int32)
+    w1[::7] += 4
+    add("int_pfor_width1_exceptions", w1, "pfor")
+    add("int_pfor_mixed_widths", (_rng(34).integers(0, 2**31, N) >> _rng(35).integers(0, 31, N)).astype(np.int32), "pfor")
+    add("int_pfor_two_pages", outliers.repeat(2)[:100000] ^ 5, "pfor")
+    add("int_pfor_delta_sorted", np.cumsum(_rng(36).integers(0, 50, N)).astype(np.int32), "pfor_delta")
+    add("int_pfor_delta_outliers", outliers, "pfor_delta")
+    add("int_rle_pfor", synth.int_rle(N), "rle(pfor,pfor)")
+    add("int_for_pfor", synth.int_for(N), "for(pfor)")
+    add("int_dict_pfor_codes", synth.int_dict(N), "dict(pfor)")
+    add("int_frequency_pfor", synth.int_frequency(N), "frequency(pfor)")
+    for n in (1, 255, 256, 257, 511, 513, 1000, 16960, 65535):
+        add(f"int_pfor_n{n}", _rng(200 + n).integers(0, 1 << 17, n).astype(np.int32), "pfor")
+        add(f"int_pfor_delta_n{n}", np.cumsum(_rng(300 + n).integers(0, 9, n)).astype(np.int32), "pfor_delta")
     # ragged sizes
     for n in (0, 1, 31, 32, 33, 63, 64, 65, 127, 128, 129, 255, 256, 257, 1000, 16960, 65535):
         add(f"int_bp_n{n}", _rng(100 + n).integers(0, 1 << 17, n).astype(np.int32), "bp")

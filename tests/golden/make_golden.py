@@ -7,7 +7,7 @@ tools/playground/for_tests.cpp:48, the generateData() pattern of tools/examples/
 the distributions of test/DatasetGenerator.cpp - plus Pseudodecimal edge values derived from
 btrblocks/scheme/double/Pseudodecimal.cpp:82-123. Expected output = input (every scheme is lossless).
 
-Usage: python tests/golden/make_golden.py   (writes tests/golden/*.npz)
+Usage: python tests/golden/make_golden.py [name ...]   (writes tests/golden/*.npz)
 """
 import os
 import sys
@@ -46,10 +46,19 @@ def vectors():
     yield "nulls_flipped", synth.int_rle(3000), synth.random_nullmap(3000, 0.8), "rle(bp,bp)"
     yield "nulls_all", synth.int_for(500), np.zeros(500, dtype=np.uint8), "for(bp)"
     yield "empty_int", np.zeros(0, dtype=np.int32), None, "auto"
+    # for_tests.cpp:48-58 runs its vector through PFOR as well as BP
+    yield "kat10_pfor", np.tile(KAT10, 40), None, "pfor"
+    outliers = rng.integers(0, 1000, 1000).astype(np.int32)
+    outliers[::37] = rng.integers(0, 2**31 - 1, outliers[::37].size).astype(np.int32)
+    yield "pfor_outliers", outliers, None, "pfor"
+    yield "pfor_delta_sorted", np.cumsum(rng.integers(0, 50, 1000)).astype(np.int32), None, "pfor_delta"
 
 
 def main():
+    only = set(sys.argv[1:])  # optional: regenerate just these fixtures
     for name, values, nullmap, spec in vectors():
+        if only and name not in only:
+            continue
         chunk = B.compress_chunk(values, nullmap, spec)
         np.savez_compressed(os.path.join(HERE, name + ".npz"), chunk=chunk, values=values,
                             nullmap=np.ones(values.size, np.uint8) if nullmap is None else nullmap,
