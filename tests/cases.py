@@ -92,6 +92,19 @@ def cases():
     edge = np.array([0.0, -0.0, 1.0, -1.5, 0.1, 0.25, 123456.789, 2147483647.0, 2147483648.0, 1e-22, 3e-22,
                      1e22, 0.30000000000000004, 5e-324, 1.7976931348623157e308, 99.99], dtype=np.float64)
     add("dbl_pseudo_edges", np.tile(edge, 64), "pseudodecimal(bp,bp,uncompressed)")
+    # exception placement against the streamed kernel's row scheduling (digits lag rows by the
+    # exceptions before them): many patches, patches bunched at either end, wide digit strings
+    add("dbl_pseudo_many_patches", synth.double_decimal(N, patch_fraction=0.45), "pseudodecimal(bp,bp,uncompressed)")
+    bunch = synth.double_decimal(N, patch_fraction=0)
+    tail_bunch = bunch.copy()
+    tail_bunch[-9000:] = 1.0 / 3.0 * np.arange(1, 9001)
+    add("dbl_pseudo_patches_at_end", tail_bunch, "pseudodecimal(bp,bp,uncompressed)")
+    head_bunch = bunch.copy()
+    head_bunch[:9000] = 1.0 / 7.0 * np.arange(1, 9001)
+    add("dbl_pseudo_patches_at_start", head_bunch, "pseudodecimal(bp,bp,uncompressed)")
+    wide = (_rng(60).integers(0, 2**31 - 1, N) >> _rng(61).integers(0, 30, N)).astype(np.float64) / 1000.0
+    add("dbl_pseudo_wide_digits", wide, "pseudodecimal(bp,bp,uncompressed)")
+    add("dbl_pseudo_two_blocks", synth.double_decimal(100000, patch_fraction=0.02), "pseudodecimal(bp,bp,uncompressed)")
     add("dbl_uncompressed", _rng(20).uniform(-1e6, 1e6, 5000), "uncompressed")
     add("dbl_onevalue", np.full(N, 3.25), "onevalue")
     add("dbl_dict_bp", synth.dictionary_values(N, 1020, dtype=np.float64), "dict(bp)")
