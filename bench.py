@@ -33,6 +33,14 @@ COLUMNS = {
     "dict": ("int_dict", "dict(bp)", 2),
     "for": ("int_for", "for(bp)", 3),
     "pseudodecimal": ("double_decimal", "pseudodecimal(bp,bp,uncompressed)", 4),
+    # nested cascades of the mixed-relation configuration (depth 3, trees the reference compressor emits)
+    "rle_dict": ("int_rle_pool", "rle(dict(bp),bp)", 7),
+    "for_rle": ("int_rle", "for(rle(bp,bp))", 8),
+    "freq_dict": ("int_frequency_pool", "frequency(dict(bp))", 9),
+    "pfor": ("int_outliers", "pfor", 10),
+    "pseudo_rle": ("double_decimal_runs", "pseudodecimal(rle(dict(bp),bp),rle(bp,bp),uncompressed)", 11),
+    "dbl_dict": ("double_dict", "dict(bp)", 12),
+    "dbl_rle": ("double_runs", "rle(uncompressed,bp)", 13),
     # engine ceilings: a pure fill (ONE_VALUE) and a pure copy (UNCOMPRESSED)
     "onevalue": ("int_constant", "onevalue", 5),
     "uncompressed": ("int_for", "uncompressed", 6),
@@ -236,7 +244,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "int32" if "pseudodecimal" not in names else "int32+f64",
+            "dtype": "int32" if all(c["raw_bytes"] == 4 * args.rows for c in cols) else "int32+f64",
             "data": "synthetic",
             "config": {
                 "workload": f"{len(names)} synthetic columns x {args.rows} rows ({','.join(c['spec'] for c in cols)}), "

@@ -232,7 +232,7 @@ const char* btr_version(void) { return "btrblocks_amd 0.1 (gfx950)"; }
 const char* btr_kernel_name(uint32_t k) {
   static const char* const names[KERNEL_KINDS] = {
       "btr_decode_int_kernel",      "btr_decode_dbl_kernel",      "btr_stream_none_kernel",  "btr_stream_add_kernel",
-      "btr_stream_dict_lds_kernel", "btr_stream_dict_glb_kernel", "btr_stream_pseudo_kernel"};
+      "btr_stream_dict_lds_kernel", "btr_stream_dict_glb_kernel", "btr_stream_pseudo_kernel", "btr_stream_dictd_kernel"};
   return k < KERNEL_KINDS ? names[k] : nullptr;
 }
 
@@ -429,7 +429,7 @@ btr_status btr_gpu_ctx_create(int device, btr_gpu_ctx** out) {
   const void* kernels[] = {(const void*)btr_decode_int_kernel,      (const void*)btr_decode_dbl_kernel,
                            (const void*)btr_stream_none_kernel,     (const void*)btr_stream_add_kernel,
                            (const void*)btr_stream_dict_lds_kernel, (const void*)btr_stream_dict_glb_kernel,
-                           (const void*)btr_stream_pseudo_kernel};
+                           (const void*)btr_stream_pseudo_kernel,   (const void*)btr_stream_dictd_kernel};
   for (const void* k : kernels) {
     hipFuncAttributes attr;
     e = hipFuncGetAttributes(&attr, k);
@@ -566,7 +566,7 @@ btr_status btr_gpu_decode(btr_gpu_ctx* ctx, btr_gpu_plan* plan, void* hip_stream
   static const Kernel kernels[KERNEL_KINDS] = {btr_decode_int_kernel,      btr_decode_dbl_kernel,
                                                btr_stream_none_kernel,     btr_stream_add_kernel,
                                                btr_stream_dict_lds_kernel, btr_stream_dict_glb_kernel,
-                                               btr_stream_pseudo_kernel};
+                                               btr_stream_pseudo_kernel,   btr_stream_dictd_kernel};
   for (uint32_t kind = 0; kind < KERNEL_KINDS; kind++) {
     const size_t n = plan->kind_begin[kind + 1] - plan->kind_begin[kind];
     if (n == 0) continue;

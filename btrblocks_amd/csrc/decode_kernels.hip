@@ -1303,6 +1303,41 @@ __device__ __forceinline__ void stream_int_bp(const Ctx& c, const Pipe& p, const
   }
 }
 
+// ---- DICT(BP) doubles (templated/DynamicDictionary.hpp:162-216): codes through the ring, 8-byte gather --
+__device__ __forceinline__ void stream_dictd(const Ctx& c, const Pipe& root, u64* __restrict__ dst, u32 jump_off) {
+  const Pipe& pc = pipe_at(c, uniform(root.a[0]));
+  const BpView bp = resolve_bp(c, pc);
+  const Tab dict = resolve_tab(c, uniform(root.a[1]));
+  const u32 n = uniform(root.count);
+  const UnpackLane u = unpack_lane();
+  const __amdgpu_buffer_rsrc_t dst_rsrc = make_rsrc(dst, bp.rounded * 8);
+  const bool in_lds = dict.loc == LOC_LDS;
+  u32 code_max = 0;
+  auto gather = [&](u32 code) {
+    code_max = code_max > code ? code_max : code;
+    code = code < dict.count ? code : dict.count - 1;
+    return in_lds ? lds64(dict.lds + 8 * code) : ldg64(dict.g + 8ull * code);
+  };
+  ring_pass(
+      c, pc, bp, jump_off, [](const ChainState& st) { return st.g; },
+      [&](u32 g_lo, u32 g_hi, u32 uw) {
+        for (u32 g = g_lo + uw; g < g_hi; g += kUnpackWaves) {
+          const u64 en = lds64(bp.index_off + 8 * g);
+          const u32 c0 = ring_extract<0>((u32)en, (u32)(en >> 32), u.sh_lo, u.pm_lo, u.k);
+          const u32 c1 = ring_extract<0>((u32)en, (u32)(en >> 32), u.sh_hi, u.pm_hi, u.k);
+          const u64 r0 = gather(c0), r1 = gather(c1);
+          const u32 o = g * (btrfmt::FBP_GROUP * 8) + 2 * u.row4;
+          u32x2 s0, s1;
+          s0.x = (u32)r0, s0.y = (u32)(r0 >> 32), s1.x = (u32)r1, s1.y = (u32)(r1 >> 32);
+          __builtin_amdgcn_raw_buffer_store_b64(s0, dst_rsrc, o, 0, kStoreNt);
+          __builtin_amdgcn_raw_buffer_store_b64(s1, dst_rsrc, o + 512, 0, kStoreNt);
+        }
+      });
+  for (u32 i = bp.rounded + threadIdx.x; i < n; i += kStreamThreads)
+    dst[i] = gather(lds32(bp.tail_off + 4 * ((i - bp.rounded) & 31)));
+  if (code_max >= dict.count) raise(c, ST_DICT_CODE);
+}
+
 // ---- PSEUDODECIMAL(BP, BP, raw patches): digits streamed through the ring -------------------------
 // double/Pseudodecimal.cpp:424-436: row i is patches[x] when its exponent is the exception code
 // (x = exceptions before row i), else double(int32 digits[i - x]) * 10^-exponent. The digit
@@ -1502,6 +1537,77 @@ __device__ __forceinline__ void mat_dbl(const Ctx& c, const DblEval& e, const Ta
   report(c, bad);
 }
 
+// Two consecutive rows per lane (16-byte stores) for table-driven double roots, the counterpart
+// of mat_int4.
+typedef u64 u64x2 __attribute__((ext_vector_type(2)));
+
+template <u32 BASE>
+__device__ __forceinline__ u64x2 eval_dbl2_base(const DblEval& e, u32 i, __amdgpu_buffer_rsrc_t seq_rsrc) {
+  u64x2 v;
+  if (BASE == B_ONE) {
+    v.x = v.y = ((u64)e.k1 << 32) | e.k0;
+  } else if (BASE == B_SEQ) {
+    const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(seq_rsrc, i * 8, 0, 0);
+    v.x = ((u64)w.y << 32) | w.x;
+    v.y = ((u64)w.w << 32) | w.z;
+  } else if (BASE == B_RLE) {
+    const u32 w = i >> 6, p = i & 63;
+    const u64 word = lds64(e.rk.bits_off + 8 * w);
+    const u32 r = lds32(e.rk.rank_off + 4 * w) + __popcll(word & ((2ull << p) - 1));
+    const u32 last = e.tab.count - 1;
+    u32 r0 = r ? r - 1 : 0;
+    u32 r1 = r0 + ((u32)(word >> (p + 1)) & 1);
+    r0 = r0 < last ? r0 : last;
+    r1 = r1 < last ? r1 : last;
+    v.x = tab_ld64(e.tab, r0);
+    v.y = tab_ld64(e.tab, r1);
+  } else {  // B_FREQ
+    const u32 w = i >> 6, p = i & 63;
+    const u64 word = lds64(e.rk.bits_off + 8 * w);
+    const u32 m = (u32)(word >> p) & 3;
+    v.x = v.y = ((u64)e.k1 << 32) | e.k0;
+    if (m) {
+      const u32 last = e.tab.count - 1;
+      u32 r = lds32(e.rk.rank_off + 4 * w) + __popcll(word & ((1ull << p) - 1));
+      if (m & 1) v.x = tab_ld64(e.tab, r < last ? r : last);
+      r += m & 1;
+      if (m & 2) v.y = tab_ld64(e.tab, r < last ? r : last);
+    }
+  }
+  return v;
+}
+
+template <u32 BASE>
+__device__ __forceinline__ void mat_dbl2(const Ctx& c, const DblEval& e, u64* __restrict__ dst, u32 count) {
+  const u32 tid = threadIdx.x;
+  const u32 pairs = count & ~1u;
+  const __amdgpu_buffer_rsrc_t seq_rsrc =
+      BASE == B_SEQ && e.tab.loc != LOC_LDS ? make_rsrc(e.tab.g, e.tab.count * 8) : make_rsrc(nullptr, 0);
+  for (u32 base = 0; base < pairs; base += kBlockThreads * 2 * kUnroll4) {
+    u64x2 v[kUnroll4];
+#pragma unroll
+    for (u32 u = 0; u < kUnroll4; u++) {
+      const u32 i = base + (u * kBlockThreads + tid) * 2;
+      v[u] = eval_dbl2_base<BASE>(e, i < pairs ? i : pairs - 2, seq_rsrc);
+    }
+#pragma unroll
+    for (u32 u = 0; u < kUnroll4; u++) {
+      const u32 i = base + (u * kBlockThreads + tid) * 2;
+      if (i < pairs) __builtin_nontemporal_store(v[u], reinterpret_cast<u64x2*>(dst + i));
+    }
+  }
+  u32 bad = 0;
+  if (tid < count - pairs) dst[pairs + tid] = eval_dbl<BASE, GEN, GEN, PS_GEN>(e, pairs + tid, bad);
+}
+
+// Whether a double root can take the two-rows-per-lane path into a 16-byte aligned output.
+__device__ __forceinline__ bool wide_rows_dbl(const DblEval& e, const Tab& out, u32 count) {
+  if (out.loc == LOC_LDS || (reinterpret_cast<u64>(out.g) & 15) != 0 || count < 2) return false;
+  if (e.base == B_SEQ) return e.tab.loc != LOC_LDS && (reinterpret_cast<u64>(e.tab.g) & 3) == 0;
+  if (e.base == B_RLE) return e.tab.count > 0;
+  return e.base == B_ONE || e.base == B_FREQ;
+}
+
 template <u32 BASE>
 __device__ __forceinline__ void mat_int_ps(const Ctx& c, const IntEval& e, const Tab& out, u32 count) {
   switch (post_signature(e)) {
@@ -1546,6 +1652,16 @@ __device__ __forceinline__ void materialize(const Ctx& c, u32 pipe_id, u32 seq_i
     }
   } else if (DOUBLE_KERNEL) {
     const DblEval e = resolve_dbl(c, pipe_id);
+    if (wide_rows_dbl(e, out, count)) {
+      u64* dst = reinterpret_cast<u64*>(const_cast<u8*>(out.g));
+      switch (e.base) {
+        case B_SEQ: mat_dbl2<B_SEQ>(c, e, dst, count); break;
+        case B_ONE: mat_dbl2<B_ONE>(c, e, dst, count); break;
+        case B_RLE: mat_dbl2<B_RLE>(c, e, dst, count); break;
+        default: mat_dbl2<B_FREQ>(c, e, dst, count); break;
+      }
+      return;
+    }
     const bool bare = e.ia.n_post == 0 && e.ib.n_post == 0;
     switch (e.base) {
       case B_SEQ: mat_dbl<B_SEQ, GEN, GEN, PS_GEN>(c, e, out, count); break;
@@ -1969,13 +2085,33 @@ __device__ __forceinline__ void stream_block(const WorkItem* __restrict__ items,
     const Step& st = step_at(c, s);
     const Tab from = resolve_tab(c, uniform(pipe_at(c, uniform(st.a[0])).a[0]));
     const Tab to = resolve_tab(c, uniform(st.a[1]));
-    for (u32 i = threadIdx.x; i < to.count; i += kStreamThreads) lds_st32(to.lds + 4 * i, ldg32(from.g + 4ull * i));
+    for (u32 i = threadIdx.x; i < to.count * (to.esize / 4); i += kStreamThreads)
+      lds_st32(to.lds + 4 * i, ldg32(from.g + 4ull * i));
   }
   __syncthreads();
   const Step& root = step_at(c, hdr.n_steps - 1);
   const u32 pipe_id = uniform(root.a[0]);
   const IntEval e = resolve_int(c, pipe_id);
   stream_int_bp<PS>(c, pipe_at(c, pipe_id), e, reinterpret_cast<u32*>(c.dst), seq_lds(c, uniform(root.a[3])));
+}
+
+// DICT(BP) double chunks: [dictionary copy into LDS] + streamed root.
+__device__ __forceinline__ void stream_dictd_block(const WorkItem* __restrict__ items, const u32* __restrict__ order,
+                                                   const u8* __restrict__ programs, u32* __restrict__ status) {
+  const u32 item = order[blockIdx.x];
+  const WorkItem it = items[item];
+  Ctx c;
+  const ProgramHeader hdr = load_program<kStreamThreads, kStreamProgBase>(it, item, programs, status, c);
+  for (u32 s = 0; s + 1 < hdr.n_steps; s++) {
+    const Step& st = step_at(c, s);
+    const Tab from = resolve_tab(c, uniform(pipe_at(c, uniform(st.a[0])).a[0]));
+    const Tab to = resolve_tab(c, uniform(st.a[1]));
+    for (u32 i = threadIdx.x; i < to.count * (to.esize / 4); i += kStreamThreads)
+      lds_st32(to.lds + 4 * i, ldg32(from.g + 4ull * i));
+  }
+  __syncthreads();
+  const Step& root = step_at(c, hdr.n_steps - 1);
+  stream_dictd(c, pipe_at(c, uniform(root.a[0])), reinterpret_cast<u64*>(c.dst), seq_lds(c, uniform(root.a[3])));
 }
 
 // PSEUDODECIMAL(BP, BP, raw patches) chunks. The program is [clear bitmap, rank, streamed root]:
@@ -2091,4 +2227,10 @@ extern "C" __global__ void __launch_bounds__(kStreamThreads)
 btr_stream_pseudo_kernel(const WorkItem* __restrict__ items, const u32* __restrict__ order,
                          const u8* __restrict__ programs, u32* __restrict__ status) {
   stream_pseudo_block(items, order, programs, status);
+}
+// DICT(BP) double columns (plan.h: KERNEL_STREAM_DICTD).
+extern "C" __global__ void __launch_bounds__(kStreamThreads)
+btr_stream_dictd_kernel(const WorkItem* __restrict__ items, const u32* __restrict__ order,
+                        const u8* __restrict__ programs, u32* __restrict__ status) {
+  stream_dictd_block(items, order, programs, status);
 }

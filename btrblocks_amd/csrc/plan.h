@@ -154,7 +154,8 @@ enum : uint32_t {
   KERNEL_STREAM_DICT_LDS = 4,  // DICT(BP), dictionary staged in LDS
   KERNEL_STREAM_DICT_GLB = 5,  // DICT(BP), dictionary read from the compressed bytes
   KERNEL_STREAM_PSEUDO = 6,    // PSEUDODECIMAL(BP,BP,raw patches) doubles: digits through the ring
-  KERNEL_KINDS = 7,
+  KERNEL_STREAM_DICTD = 7,     // DICT(BP) doubles, dictionary staged in LDS or read from the compressed bytes
+  KERNEL_KINDS = 8,
 };
 
 constexpr uint32_t kBlockThreads = 256;

@@ -28,7 +28,8 @@ constexpr int ST_CORRUPT = 2, ST_UNSUPPORTED = 3, ST_MISALIGNED = 6;
 constexpr int kMaxDepth = 8;
 // Optional tables (materialized children, dictionary copies) go to LDS while the workgroup's
 // total stays under this; beyond it they live in the chunk's HBM scratch slice.
-constexpr uint32_t kLdsSoftCap = 52 * 1024;  // three workgroups per CU
+constexpr uint32_t kLdsSoftCapGeneric = 52 * 1024;  // three workgroups per CU
+constexpr uint32_t kLdsSoftCapStream = 60 * 1024;   // two 512-thread workgroups per CU when a dictionary needs it
 constexpr uint32_t kDictLdsMaxBytes = 32 * 1024;
 
 struct Builder {
@@ -88,9 +89,19 @@ struct Builder {
 
   // The sequence holding a pipe's values: the pipe's own source when it is a bare array,
   // otherwise a new table filled by a materialize step.
-  uint32_t as_seq(uint32_t pipe) {
+  uint32_t as_seq(uint32_t pipe, uint32_t rows_reading_it = 0) {
     const Pipe& p = pipes[pipe];
-    if (p.base == B_SEQ && p.n_post == 0) return p.a[0];
+    if (p.base == B_SEQ && p.n_post == 0) {
+      // a raw array inside the compressed bytes that every row gathers from (run values,
+      // exception lists): worth a copy into LDS when it is small against the rows it serves
+      const Seq& s = seqs[p.a[0]];
+      if (s.loc != LOC_SRC || rows_reading_it < 2 * s.count || (uint64_t)s.count * s.esize > kDictLdsMaxBytes ||
+          s.count == 0)
+        return p.a[0];
+      const uint32_t lds = add_seq(LOC_LDS, 0, s.count, s.esize);
+      add_step(S_MATERIALIZE, pipe, lds);
+      return lds;
+    }
     const uint32_t s = add_seq(LOC_LDS, 0, p.count, p.is_double ? 8 : 4);
     add_step(S_MATERIALIZE, pipe, s);
     return s;
@@ -351,7 +362,7 @@ struct Builder {
     add_step(S_BITMAP_CLEAR, NONE, bm.bits);
     add_step(S_BITMAP_STARTS, lengths, bm.bits, NONE, n, runs);
     add_step(S_BITMAP_RANK, NONE, bm.bits, bm.rank, n, runs, ST_RLE_COUNTS);
-    const uint32_t values = as_seq(vp);
+    const uint32_t values = as_seq(vp, n);
     const uint32_t p = add_pipe(B_RLE, IS_DOUBLE, n);
     pipes[p].a[0] = bm.bits;
     pipes[p].a[1] = bm.rank;
@@ -572,6 +583,17 @@ void build_program(const ColumnSource& src, BuiltProgram& out) {
         kernel = KERNEL_STREAM_ADD;
       else
         kernel = KERNEL_STREAM_DICT_LDS;  // corrected below once table placement is known
+    } else if (src.column_type == COL_DOUBLE && rp.base == B_DICTD && !src.want_nullmap && n > 0 &&
+               bld.bp_steps.size() == 1 && bld.pipes[rp.a[0]].base == B_BP && bld.pipes[rp.a[0]].n_post == 0 &&
+               bld.seqs[rp.a[1]].count > 0 &&
+               std::all_of(bld.steps.begin(), bld.steps.end(), [&](const Step& st) {
+                 return st.kind == S_MATERIALIZE && bld.pipes[st.a[0]].base == B_SEQ && bld.pipes[st.a[0]].n_post == 0;
+               })) {
+      // DICT(BP) doubles: codes through the ring, 8-byte dictionary gather
+      bld.bp_steps.clear();
+      bld.add_step(S_STREAM_ROOT, root, dst);
+      prog_base = kStreamProgBase;
+      kernel = KERNEL_STREAM_DICTD;
     } else if (src.column_type == COL_DOUBLE && rp.base == B_PSEUDO && rp.a[0] != NONE && !src.want_nullmap &&
                n > 0 && n / 64 + 1 <= 4096 && bld.bp_steps.size() == 2 && bld.steps.size() == 3 &&
                bld.pipes[rp.a[0]].base == B_BP && bld.pipes[rp.a[0]].n_post == 0 &&
@@ -656,7 +678,7 @@ void build_program(const ColumnSource& src, BuiltProgram& out) {
   for (auto& s : bld.seqs)
     if (s.loc == LOC_LDS && !s.must_lds) {
       const uint64_t bytes = align_up(s.count * s.esize, 16);
-      if (table_base + lds + bytes <= kLdsSoftCap) {
+      if (table_base + lds + bytes <= (kernel <= KERNEL_GENERIC_DBL ? kLdsSoftCapGeneric : kLdsSoftCapStream)) {
         s.off = (uint32_t)lds;
         lds += bytes;
       } else {
@@ -670,6 +692,16 @@ void build_program(const ColumnSource& src, BuiltProgram& out) {
                                         std::to_string(table_base + lds) + " bytes)");
   if (scratch > 0xFFFFFFFFull) throw PlanError(ST_UNSUPPORTED, "scratch need above 4 GiB");
 
+  if (kernel == KERNEL_STREAM_DICTD && bld.seqs[bld.pipes[root].a[1]].loc == LOC_SCRATCH) {
+    // the LDS copy did not fit: gather from the dictionary inside the compressed bytes instead
+    for (size_t k = 0; k < bld.steps.size(); k++)
+      if (bld.steps[k].kind == S_MATERIALIZE && bld.steps[k].a[1] == bld.pipes[root].a[1]) {
+        bld.pipes[root].a[1] = bld.pipes[bld.steps[k].a[0]].a[0];
+        bld.steps.erase(bld.steps.begin() + k);
+        scratch = 0;
+        break;
+      }
+  }
   if (kernel == KERNEL_STREAM_DICT_LDS) {
     const Seq& dict = bld.seqs[bld.pipes[root].post[0].arg];
     if (dict.count == 0) throw PlanError(ST_CORRUPT, "empty dictionary");

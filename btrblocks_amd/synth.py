@@ -96,3 +96,65 @@ def dictionary_values(n, distinct, seed=7, dtype=np.int32):
 def random_nullmap(n, valid_fraction, seed=8):
     rng = np.random.default_rng(seed)
     return (rng.random(n) < valid_fraction).astype(np.uint8)
+
+
+def _run_lengths(rng, n, lo=16, hi=65):
+    runs = int(n / ((lo + hi - 1) / 2) * 1.05) + 64
+    lengths = rng.integers(lo, hi, size=runs)
+    while int(lengths.sum()) < n:
+        lengths = np.concatenate([lengths, rng.integers(lo, hi, size=runs // 8 + 64)])
+    return lengths
+
+
+def double_decimal_runs(n, seed=11, patch_fraction=0.01):
+    """Two-decimal prices from a pool of 4096 values in runs of 16..64, with non-decimal patches."""
+    rng = np.random.default_rng(seed)
+    lengths = _run_lengths(rng, n)
+    pool = rng.integers(0, 10_000_000, size=4096).astype(np.float64) * 0.01
+    out = np.repeat(pool[rng.integers(0, pool.size, size=lengths.size)], lengths)[:n].copy()
+    m = int(n * patch_fraction)
+    if m:
+        rows = rng.choice(n, size=m, replace=False)
+        out[rows] = (rows.astype(np.float64) + 1.0) / 3.0
+    return out
+
+
+def double_dict(n, seed=12, distinct=4095):
+    """`distinct` random doubles drawn uniformly."""
+    rng = np.random.default_rng(seed)
+    dictionary = np.unique(rng.random(distinct * 2))[:distinct] * 1e6
+    return dictionary[rng.integers(0, dictionary.size, size=n)]
+
+
+def double_runs(n, seed=13):
+    """random doubles in runs of uniform length 16..64."""
+    rng = np.random.default_rng(seed)
+    lengths = _run_lengths(rng, n)
+    return np.repeat(rng.random(lengths.size) * 1e6, lengths)[:n].copy()
+
+
+def int_rle_pool(n, seed=7, distinct=1000):
+    """runs of uniform length 16..64 over a pool of `distinct` random 31-bit values."""
+    rng = np.random.default_rng(seed)
+    lengths = _run_lengths(rng, n)
+    pool = rng.integers(0, 2**31 - 1, size=distinct).astype(np.int32)
+    return np.ascontiguousarray(np.repeat(pool[rng.integers(0, distinct, size=lengths.size)], lengths)[:n])
+
+
+def int_outliers(n, seed=10, bits=10, outlier_fraction=0.02):
+    """u % 2^bits with a few 31-bit outliers: the shape patched bit-packing is made for."""
+    rng = np.random.default_rng(seed)
+    out = rng.integers(0, 1 << bits, size=n).astype(np.int32)
+    rows = rng.choice(n, size=max(1, int(n * outlier_fraction)), replace=False)
+    out[rows] = rng.integers(0, 2**31 - 1, size=rows.size).astype(np.int32)
+    return out
+
+
+def int_frequency_pool(n, seed=9, top_fraction=0.95, distinct=500):
+    """one dominant value; the exceptions come from a pool of `distinct` random values."""
+    rng = np.random.default_rng(seed)
+    out = np.full(n, 123456, dtype=np.int32)
+    rows = rng.choice(n, size=int(n * (1 - top_fraction)), replace=False)
+    pool = rng.integers(0, 2**31 - 1, size=distinct).astype(np.int32)
+    out[rows] = pool[rng.integers(0, distinct, size=rows.size)]
+    return out
