@@ -115,6 +115,7 @@ struct Ctx {
   u32 red_off;                         // 64 bytes of LDS for block-wide reductions
   u32 consts_off;                      // LDS byte offset of the program's constant words
   u32 debug;                           // WorkItem::debug_flags
+  u64 debug_buf;                       // WorkItem::debug_buf
 };
 
 __device__ __forceinline__ const Step& step_at(const Ctx& c, u32 i) {
@@ -128,6 +129,11 @@ __device__ __forceinline__ const Seq& seq_at(const Ctx& c, u32 i) {
 }
 __device__ __forceinline__ void raise(const Ctx& c, u32 bits) { atomicOr(c.status, bits); }
 // Diagnostics: timestamp `slot` of this work item (constant 100 MHz clock), thread 0 only.
+#define BTR_STAMP(c, slot)                                                              \
+  do {                                                                                  \
+    if (((c).debug & 8) && threadIdx.x == 0 && (slot) < kDebugSlots)                    \
+      reinterpret_cast<u32*>((c).debug_buf)[slot] = (u32)wall_clock64();                \
+  } while (0)
 __device__ __forceinline__ void stamp(const WorkItem& it, u32 slot) {
   if ((it.debug_flags & 8) && threadIdx.x == 0 && slot < kDebugSlots)
     reinterpret_cast<u32*>(it.debug_buf)[slot] = (u32)wall_clock64();
@@ -1823,7 +1829,7 @@ __device__ __forceinline__ void vbyte_tail_decode(const Ctx& c, __amdgpu_buffer_
 }
 
 __device__ __forceinline__ void pfor_decode(const Ctx& c, const Step& s) {
-  const u32 tid = threadIdx.x, lane = tid & 63, wave = uniform(tid >> 6);
+  const u32 tid = threadIdx.x;
   const u8* base = c.src + uniform(s.a[0]);
   const u32 W = uniform(s.a[1]);
   const u32 desc0 = c.consts_off + 4 * uniform(s.a[2]);
@@ -1831,7 +1837,7 @@ __device__ __forceinline__ void pfor_decode(const Ctx& c, const Step& s) {
   const bool delta = (uniform(s.a[3]) >> 31) != 0;
   const Tab out = resolve_tab(c, uniform(s.a[4]));
   const u32 work = seq_lds(c, uniform(s.a[5]));
-  const u32 table_off = work, stage_off = work + 4096 + 1024 * wave, tail_off = work + 8192;
+  const u32 table_off = work, bytes_lds = work + 4096, tail_off = work + 8192;
   const u32 n = out.count;
   const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(base, W * 4);
   u32 bad = 0;
@@ -1841,21 +1847,34 @@ __device__ __forceinline__ void pfor_decode(const Ctx& c, const Step& s) {
               bytes_off = uniform(lds32(d + 12)), bytes_size = uniform(lds32(d + 16));
     const u32 blocks = len / btrfmt::PFOR_BLOCK;
     // 1. the byte container is a chain of variable-length records {b, exception count, [max bits,
-    //    positions...]}: one lane follows it and notes {b, count, exception width}, the offset of
-    //    the position bytes and the first word of the block's packs
+    //    positions...]}: staged in LDS when it fits, then one lane follows it and notes {b, count,
+    //    exception width}, the offset of the position bytes and the first word of the block's packs
+    const bool staged = bytes_size <= 4096;
+    if (staged) {
+      const u32 skew = bytes_off & 3;  // bytes_off is word aligned by construction; keep it general
+      for (u32 w = tid; w * 4 < bytes_size + skew; w += kBlockThreads)
+        lds_st32(bytes_lds + 4 * w, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (bytes_off - skew) + 4 * w, 0, 0));
+      __syncthreads();
+    }
+    BTR_STAMP(c, 8);
     if (tid == 0) {
+      const u32 skew = bytes_off & 3;
+      auto byte_at = [&](u32 o) -> u32 { return staged ? lds_raw[bytes_lds + skew + o] : base[bytes_off + o]; };
       u32 o = 0, dw = data_word;
       for (u32 r = 0; r < blocks; r++) {
-        u32 b = 0, cex = 0, k = 0;
-        if (o + 2 <= bytes_size) {
-          b = base[bytes_off + o];
-          cex = base[bytes_off + o + 1];
+        u32 b = 0, cex = 0, k = 0, maxb = 0;
+        if (o + 3 <= bytes_size) {
+          b = byte_at(o);
+          cex = byte_at(o + 1);
+          maxb = byte_at(o + 2);
+        } else if (o + 2 <= bytes_size) {
+          b = byte_at(o);
+          cex = byte_at(o + 1);
         } else {
           bad = 1;
         }
         o += 2;
         if (cex) {
-          const u32 maxb = o < bytes_size ? base[bytes_off + o] : 0u;
           if (maxb <= b || maxb > 32) bad = 1;
           k = maxb > b ? maxb - b : 1;
           o += 1;
@@ -1873,6 +1892,7 @@ __device__ __forceinline__ void pfor_decode(const Ctx& c, const Step& s) {
       if (o > bytes_size) bad = 1;
     }
     __syncthreads();
+    BTR_STAMP(c, 9);
     // 2. index of a block's first exception inside its width class: exceptions of the same width
     //    in the blocks before it
     for (u32 r = tid; r < blocks; r += kBlockThreads) {
@@ -1884,50 +1904,58 @@ __device__ __forceinline__ void pfor_decode(const Ctx& c, const Step& s) {
       }
       lds_st32(table_off + 16 * r + 8, before);
     }
-    __syncthreads();
-    // 3. a wave per block: unpack 256 values into its staging area, patch the exceptions in, store
-    for (u32 r = wave; r < blocks; r += kBlockThreads / 64) {
-      const u32 e = uniform(lds32(table_off + 16 * r)), pos_off = uniform(lds32(table_off + 16 * r + 4)),
-                ex0 = uniform(lds32(table_off + 16 * r + 8)), dw = uniform(lds32(table_off + 16 * r + 12));
+    BTR_STAMP(c, 10);
+    // 3. the packed values of all blocks, consecutive rows on consecutive lanes; sixteen loads
+    //    in flight per lane
+    constexpr u32 kPforUnroll = 8;
+    for (u32 i0 = 0; i0 < len; i0 += kBlockThreads * kPforUnroll) {
+      u32 lo[kPforUnroll], hi[kPforUnroll], bw[kPforUnroll];
+#pragma unroll
+      for (u32 q = 0; q < kPforUnroll; q++) {
+        const u32 i = i0 + q * kBlockThreads + tid;
+        const u32 r = (i < len ? i : len - 1) >> 8;
+        const u32 b = lds32(table_off + 16 * r) & 0xFF, dw = lds32(table_off + 16 * r + 12);
+        const u32 bit = ((i & 127) >> 2) * b;
+        const u32 w = dw + ((i >> 7) & 1) * 4 * b + 4 * (bit >> 5) + (i & 3);
+        lo[q] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, w * 4, 0, 0);
+        hi[q] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, (w + 4) * 4, 0, 0);
+        bw[q] = b | (bit << 8);
+      }
+#pragma unroll
+      for (u32 q = 0; q < kPforUnroll; q++) {
+        const u32 i = i0 + q * kBlockThreads + tid;
+        const u32 b = bw[q] & 0xFF;
+        const u32 x = __builtin_amdgcn_alignbit(hi[q], lo[q], bw[q] >> 8);
+        if (i < len) tab_st32(out, first + i, b >= 32 ? x : (x & ((1u << b) - 1u)));
+      }
+    }
+    __syncthreads();  // also orders the stores above before the patches below
+    BTR_STAMP(c, 11);
+    // 4. exceptions: one thread per block ORs (value >> b) << b back in, by position
+    for (u32 r = tid; r < blocks; r += kBlockThreads) {
+      const u32 e = lds32(table_off + 16 * r), pos_off = lds32(table_off + 16 * r + 4), ex0 = lds32(table_off + 16 * r + 8);
       const u32 b = e & 0xFF, cex = (e >> 8) & 0xFF, k = e >> 16;
-#pragma unroll
-      for (u32 q = 0; q < 4; q++) {
-        const u32 i = lane + 64 * q;
-        lds_st32(stage_off + 4 * i, simd_pack_get(rsrc, dw + (i >> 7) * 4 * b, b, i & 127));
-      }
-      // other lanes patch this lane's staged values: the wave's LDS accesses are served in program
-      // order, the compiler must keep that order (and not forward the staged value in a register)
-      __builtin_amdgcn_wave_barrier();
-      asm volatile("" ::: "memory");
-      if (cex) {
-        const u32 cls_word = k >= 2 ? uniform(lds32(d + 4 * (5 + k - 2))) : 0u;
-        const u32 cls_size = k >= 2 ? uniform(lds32(d + 4 * (5 + 31 + k - 2))) : 0u;
-        const u32 full = cls_size & ~127u;
-        for (u32 x = lane; x < cex; x += 64) {
-          const u32 pos = base[pos_off + x];
-          u32 v = 1;
-          if (k >= 2) {
-            const u32 q = ex0 + x;
-            if (q >= cls_size) {
-              bad = 1;
-              v = 0;
-            } else if (q < full) {
-              v = simd_pack_get(rsrc, cls_word + (q >> 7) * 4 * k, k, q & 127);
-            } else {
-              const u32 qq = q - full;
-              v = bp_extract(rsrc, cls_word + (full >> 7) * 4 * k + (qq >> 5) * k, k, qq & 31);
-            }
+      if (!cex || b >= 32) continue;
+      const u32 cls_word = k >= 2 ? lds32(d + 4 * (5 + k - 2)) : 0u;
+      const u32 cls_size = k >= 2 ? lds32(d + 4 * (5 + 31 + k - 2)) : 0u;
+      const u32 full = cls_size & ~127u;
+      for (u32 x = 0; x < cex; x++) {
+        const u32 pos = base[pos_off + x];
+        u32 v = 1;
+        if (k >= 2) {
+          const u32 q = ex0 + x;
+          if (q >= cls_size) {
+            bad = 1;
+            v = 0;
+          } else if (q < full) {
+            v = simd_pack_get(rsrc, cls_word + (q >> 7) * 4 * k, k, q & 127);
+          } else {
+            const u32 qq = q - full;
+            v = bp_extract(rsrc, cls_word + (full >> 7) * 4 * k + (qq >> 5) * k, k, qq & 31);
           }
-          const u32 a = stage_off + 4 * pos;
-          lds_st32(a, lds32(a) | (b < 32 ? v << b : 0u));
         }
-      }
-      __builtin_amdgcn_wave_barrier();
-      asm volatile("" ::: "memory");
-#pragma unroll
-      for (u32 q = 0; q < 4; q++) {
-        const u32 i = lane + 64 * q;
-        tab_st32(out, first + r * btrfmt::PFOR_BLOCK + i, lds32(stage_off + 4 * i));
+        const u32 at = first + r * btrfmt::PFOR_BLOCK + pos;
+        tab_st32(out, at, tab_ld32(out, at) | (v << b));
       }
     }
     __syncthreads();
@@ -2069,6 +2097,7 @@ __device__ __forceinline__ ProgramHeader load_program(const WorkItem& it, u32 it
   c.red_off = hdr.table_base - 64;
   c.consts_off = BASE + uniform(hdr.consts_off);
   c.debug = it.debug_flags;
+  c.debug_buf = it.debug_buf;
   return hdr;
 }
 
