@@ -99,6 +99,9 @@ def main():
     ap.add_argument("--cpu-sample-chunks", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--verify", action="store_true", help="compare a sample of chunks with the oracle")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
+    ap.add_argument("--one-device", action="store_true",
+                    help="rehearsal on a one-GPU box: every rank uses cuda:0 (needs --backend gloo)")
     args = ap.parse_args()
 
     import torch
@@ -107,11 +110,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.one_device:
+        local_rank = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    red_dev = dev if args.backend == "nccl" else torch.device("cpu")  # where the two scalar reductions live
 
     import btrblocks_amd as B
     from btrblocks_amd import api
@@ -180,10 +189,10 @@ def main():
         p.check(stream)
 
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        tot = torch.tensor([float(out_bytes)], dtype=torch.float64, device=dev)
+        tot = torch.tensor([float(out_bytes)], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         total_out = float(tot.item())
     else:

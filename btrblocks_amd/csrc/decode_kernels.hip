@@ -1683,6 +1683,10 @@ __device__ __forceinline__ void materialize(const Ctx& c, u32 pipe_id, u32 seq_i
       case B_PSEUDO:
         if (e.ib.base == B_BP && (e.ia.base == B_BP || e.k0 == 0) && bare)
           mat_dbl<B_PSEUDO, B_BP, B_BP, PS_NONE>(c, e, out, count);
+        else if (e.ib.base == B_RLE && (e.ia.base == B_RLE || e.k0 == 0) && bare)
+          mat_dbl<B_PSEUDO, B_RLE, B_RLE, PS_NONE>(c, e, out, count);
+        else if (e.ib.base == B_RLE && e.ia.base == B_BP && bare)
+          mat_dbl<B_PSEUDO, B_BP, B_RLE, PS_NONE>(c, e, out, count);
         else
           mat_dbl<B_PSEUDO, GEN, GEN, PS_GEN>(c, e, out, count);
         break;
