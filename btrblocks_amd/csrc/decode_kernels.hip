@@ -2024,12 +2024,22 @@ __device__ __forceinline__ void bitmap_eq(const Ctx& c, const Step& s) {
     return;
   }
   u32 bad = 0;
-  for (u32 base = 0; base < nbits; base += THREADS) {
-    const u32 i = base + threadIdx.x;
-    const u32 ii = i < nbits ? i : nbits - 1;
-    const u32 v = eval_int<GEN, true, PS_GEN>(e, ii, bad);
-    const u64 m = __ballot(i < nbits && v == value);
-    if (lane == 0 && (i >> 6) <= (nbits >> 6)) lds_st64(bits_off + 8 * (i >> 6), m);
+  constexpr u32 kEqUnroll = 4;  // independent rows in flight per lane: the lookups are LDS-latency chains
+  for (u32 base = 0; base < nbits; base += THREADS * kEqUnroll) {
+    u32 v[kEqUnroll];
+#pragma unroll
+    for (u32 q = 0; q < kEqUnroll; q++) {
+      const u32 i = base + q * THREADS + threadIdx.x;
+      const u32 ii = i < nbits ? i : nbits - 1;
+      v[q] = (e.base == B_RLE && e.n_post == 0) ? eval_int<B_RLE, true, PS_NONE>(e, ii, bad)
+                                                : eval_int<GEN, true, PS_GEN>(e, ii, bad);
+    }
+#pragma unroll
+    for (u32 q = 0; q < kEqUnroll; q++) {
+      const u32 i = base + q * THREADS + threadIdx.x;
+      const u64 m = __ballot(i < nbits && v[q] == value);
+      if (lane == 0 && (i >> 6) <= (nbits >> 6) && (i >> 6) < words) lds_st64(bits_off + 8 * (i >> 6), m);
+    }
   }
   report(c, bad);
 }
