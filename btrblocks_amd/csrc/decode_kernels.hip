@@ -2232,7 +2232,7 @@ __device__ __forceinline__ void decode_block(const WorkItem* __restrict__ items,
 
 // `order` lists the work items this launch decodes (integer and double columns are launched
 // separately); status words are indexed by work item.
-extern "C" __global__ void __launch_bounds__(kBlockThreads)
+extern "C" __global__ void __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(6, 8)))
 btr_decode_int_kernel(const WorkItem* __restrict__ items, const u32* __restrict__ order,
                       const u8* __restrict__ programs, u32* __restrict__ status) {
   decode_block<false>(items, order, programs, status);

@@ -39,6 +39,7 @@ struct Builder {
   std::vector<Seq> seqs;
   std::vector<uint32_t> consts;        // constant words appended to the program
   std::vector<uint32_t> pfor_outputs;  // sequences filled by S_PFOR_DECODE steps
+  std::vector<uint32_t> transient;     // tables consumed by the step right after the one that fills them
   uint64_t needed = 0;
   uint32_t max_depth = 0;
 
@@ -355,8 +356,10 @@ struct Builder {
     const uint32_t vp = IS_DOUBLE ? dbl_node(data, vs, runs, depth + 1, dv)
                                   : int_node(data, vs, runs, false, depth + 1, dv);
     const uint32_t cp = int_node(data + counts_off, cs_code, runs, false, depth + 1, dc);
-    // Run lengths are always copied: the start-flag step scans them in place.
+    // Run lengths are always copied: the start-flag step scans them in place. The copy is dead
+    // after that step, so the length tables of all RLE nodes of a program share one region.
     const uint32_t lengths = add_seq(LOC_LDS, 0, runs, 4);
+    transient.push_back(lengths);
     add_step(S_MATERIALIZE, cp, lengths);
     const Bitmap bm = add_bitmap(n);
     add_step(S_BITMAP_CLEAR, NONE, bm.bits);
@@ -552,7 +555,7 @@ uint32_t align_up(uint32_t v, uint32_t a) { return (v + a - 1) / a * a; }
 void build_program(const ColumnSource& src, BuiltProgram& out) {
   if (src.column_type != COL_INTEGER && src.column_type != COL_DOUBLE)
     throw PlanError(ST_UNSUPPORTED, "only integer and double columns are decoded on the GPU");
-  Builder bld{src, {}, {}, {}, {}, {}, {}, 0, 0};
+  Builder bld{src, {}, {}, {}, {}, {}, {}, {}, 0, 0};
   const uint32_t n = src.tuple_count;
   std::string desc;
   uint32_t root;
@@ -674,6 +677,19 @@ void build_program(const ColumnSource& src, BuiltProgram& out) {
         s.off = (uint32_t)lds;
         lds += align_up(s.count * s.esize, 16);
       }
+  }
+  {
+    // one shared region for the transient tables, sized for the largest
+    uint64_t shared = 0;
+    for (uint32_t id : bld.transient) shared = std::max<uint64_t>(shared, align_up(bld.seqs[id].count * bld.seqs[id].esize, 16));
+    const uint32_t cap = kernel <= KERNEL_GENERIC_DBL ? kLdsSoftCapGeneric : kLdsSoftCapStream;
+    if (shared && table_base + lds + shared <= cap) {
+      for (uint32_t id : bld.transient) {
+        bld.seqs[id].off = (uint32_t)lds;
+        bld.seqs[id].must_lds = 2;  // placed
+      }
+      lds += shared;
+    }
   }
   for (auto& s : bld.seqs)
     if (s.loc == LOC_LDS && !s.must_lds) {
