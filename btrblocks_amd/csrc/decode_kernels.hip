@@ -1944,7 +1944,7 @@ __device__ __forceinline__ void pfor_decode(const Ctx& c, const Step& s) {
       const u32 cls_size = k >= 2 ? lds32(d + 4 * (5 + 31 + k - 2)) : 0u;
       const u32 full = cls_size & ~127u;
       for (u32 x = 0; x < cex; x++) {
-        const u32 pos = base[pos_off + x];
+        const u32 pos = __builtin_amdgcn_raw_buffer_load_b8(rsrc, pos_off + x, 0, 0);  // past the payload: 0
         u32 v = 1;
         if (k >= 2) {
           const u32 q = ex0 + x;

@@ -125,3 +125,32 @@ def test_cpp_interface_round_trip(spec):
     r = subprocess.run([exe, "640000", spec], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "decompressed data matches original data" in r.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("spec,gen", [
+    ("rle(bp,bp)", "int_rle"), ("dict(bp)", "int_dict"), ("pfor", "int_outliers"), ("rle(pfor,pfor)", "int_rle"),
+    ("frequency(bp)", "int_frequency"), ("pseudodecimal(bp,bp,uncompressed)", "double_decimal"),
+    ("dict(bp)", "double_dict"), ("rle(uncompressed,bp)", "double_runs"),
+])
+def test_corrupted_payloads_never_fault(gpu_ctx, spec, gen):
+    """Random damage anywhere behind the chunk header: the decode either completes (with whatever
+    values the damaged stream describes) or reports BTR_ERR_CORRUPT / BTR_ERR_UNSUPPORTED; it never
+    reads or writes outside its buffers."""
+    values = getattr(synth, gen)(65536)
+    chunk = B.compress_chunk(values, None, spec)
+    import zlib
+    rng = np.random.default_rng(zlib.crc32((spec + gen).encode()))
+    for trial in range(6):
+        bad = chunk.copy()
+        for _ in range(int(rng.integers(1, 4))):
+            lo = 12 + int(rng.integers(0, bad.size - 12 - 8))
+            bad[lo:lo + 8] = rng.integers(0, 256, 8).astype(np.uint8)
+        try:
+            out = gpu_ctx.decode_chunk_host(bad)
+            assert out.shape == (65536,)
+        except B.BtrError as e:
+            assert e.status in (2, 3, 6), e
+    # the undamaged chunk still decodes bit-exactly afterwards
+    out = gpu_ctx.decode_chunk_host(chunk)
+    assert np.array_equal(np.asarray(out).view(np.uint8), values.view(np.uint8))
