@@ -1,28 +1,32 @@
-// HIP decode kernels for gfx950 (MI355X): one 256-thread workgroup per compressed column chunk,
-// interpreting the flat program compiled by plan_builder.cpp (plan.h).
+// HIP decode kernels for gfx950 (MI355X): one workgroup per compressed column chunk, interpreting
+// the flat program compiled by plan_builder.cpp (plan.h).
 //
 // What it replaces in the reference: the recursive virtual decompress() cascade
 // (btrblocks/scheme/CompressionScheme.hpp:37-41, 70-74) with its scheme bodies
 //   FastPFor FastBinaryPacking<32>+VariableByte decodeArray (via btrblocks/extern/FastPFOR.cpp:47-53)
+//   FastPFor SIMDFastPFor<8>+VariableByte decodeArray (via btrblocks/extern/FastPFOR.cpp:20-31),
+//   integer/PBP.cpp:37-49, 92-109,
 //   templated/DynamicDictionary.hpp:108-216, templated/RLE.hpp:133-250,
 //   templated/Frequency.hpp:99-136, templated/FixedDictionary.hpp:56-71,
 //   integer/FOR.cpp:46-65, integer/OneValue.cpp:30-39, double/Pseudodecimal.cpp:348-452,
 //   double/DoubleBP.cpp:41-57, extern/RoaringBitmap.cpp:32-114 (nullmap expansion).
 //
-// Shape of the computation (HBM-bound integer work, no MFMA):
-//   1. the program is copied into LDS;
-//   2. every bit-packed stream gets a group index {word offset, width header} in LDS: the
-//      FastBinaryPacking layout interleaves one header word per 128 values with the payload, so
-//      header positions form a chain; one wave per stream walks it through 256-word register
-//      windows (coalesced, prefetched loads; wave-uniform readlane steps), different streams on
-//      different waves;
-//   3. short child streams (run lengths/values, exception lists, patches) are materialized into
-//      LDS (or an HBM scratch slice), start-flag / exception bitmaps get a popcount rank table;
-//   4. the root pipe is evaluated row by row - lane i of a wave produces row base+i, so stores
-//      are contiguous - with full-length children (codes, deltas, digits, exponents) bit-unpacked
-//      on the fly from the compressed stream; nothing but the decoded column is written to HBM.
-// The evaluation loops are instantiated per base kind so that each loop only keeps the state
-// of its own scheme in registers; integer and double columns run in separate kernels.
+// Two families of kernels (HBM-bound integer work, no MFMA):
+//  * generic kernels (256 threads) interpret any program:
+//    1. the program is copied into LDS;
+//    2. every bit-packed stream gets a group index {word offset, width header} in LDS: the
+//       FastBinaryPacking layout interleaves one header word per 128 values with the payload, so
+//       header positions form a chain; one wave per stream resolves it batch by batch (walk_chain),
+//       different streams on different waves;
+//    3. short child streams (run lengths/values, exception lists, patches) are materialized into
+//       LDS (or an HBM scratch slice), start-flag / exception bitmaps get a popcount rank table;
+//    4. the root pipe is evaluated row by row - consecutive rows on consecutive lanes, several
+//       rows per lane for table-driven bases - with full-length children (codes, deltas, digits,
+//       exponents) bit-unpacked on the fly; nothing but the decoded column is written to HBM.
+//  * stream kernels (512 threads) decode roots that read one full-length bit-packed stream: the
+//    payload goes through an LDS ring exactly once (ring_pass), indexed and unpacked on the way.
+// The evaluation loops are instantiated per base kind and post-op signature so that each loop only
+// keeps the state of its own scheme in registers; everything is force-inlined.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 

@@ -4,7 +4,7 @@
 // A `Spec` names the cascade to emit: either a forced tree such as rle(dict(bp),bp) or `auto`,
 // which runs a deterministic sample-based picker in the spirit of
 // btrblocks/compression/SchemePicker.hpp:70-221 (the reference samples at random positions,
-// so its choices are not reproducible).
+// so its choices are not reproducible; this picker samples at fixed, evenly spaced positions).
 #pragma once
 #include <cstddef>
 #include <cstdint>

@@ -93,7 +93,7 @@ def test_malformed_streams_are_reported_not_crashed(gpu_ctx):
 
 
 def test_full_size_column_properties(gpu_ctx):
-    """BASELINE size (1 GiB raw, 4096 blocks): lossless against the generator, checked by a
+    """Full benchmark size (1 GiB raw, 4096 blocks): lossless against the generator, checked by a
     64-bit checksum of checksums computed on the device, plus a sample of blocks against the oracle."""
     import torch
     rows = 268_435_456
