@@ -1845,7 +1845,8 @@ __device__ __forceinline__ void pfor_decode(const Ctx& c, const Step& s) {
   const bool delta = (uniform(s.a[3]) >> 31) != 0;
   const Tab out = resolve_tab(c, uniform(s.a[4]));
   const u32 work = seq_lds(c, uniform(s.a[5]));
-  const u32 table_off = work, bytes_lds = work + 4096, tail_off = work + 8192;
+  const u32 table_off = work, bytes_lds = work + 4096, tail_off = work + 8192, packed_lds = work + 9472,
+            jump_lds = work + 17664, pos_lds = work + 26880;
   const u32 n = out.count;
   const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(base, W * 4);
   u32 bad = 0;
@@ -1855,29 +1856,88 @@ __device__ __forceinline__ void pfor_decode(const Ctx& c, const Step& s) {
               bytes_off = uniform(lds32(d + 12)), bytes_size = uniform(lds32(d + 16));
     const u32 blocks = len / btrfmt::PFOR_BLOCK;
     // 1. the byte container is a chain of variable-length records {b, exception count, [max bits,
-    //    positions...]}: staged in LDS when it fits, then one lane follows it and notes {b, count,
-    //    exception width}, the offset of the position bytes and the first word of the block's packs
+    //    positions...]}. Staged in LDS (when it fits) the chain is resolved by pointer doubling:
+    //    J0[o] = o + length of the record that would start at byte o; after round t thread r <
+    //    2^(t+1) knows the offset of record r. Otherwise one lane follows it through global memory.
+    //    Each block notes {b, count, exception width}, the offset of its position bytes and (below)
+    //    the first word of its packs.
     const bool staged = bytes_size <= 4096;
+    const u32 skew = bytes_off & 3;  // bytes_off is word aligned by construction; keep it general
     if (staged) {
-      const u32 skew = bytes_off & 3;  // bytes_off is word aligned by construction; keep it general
       for (u32 w = tid; w * 4 < bytes_size + skew; w += kBlockThreads)
         lds_st32(bytes_lds + 4 * w, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (bytes_off - skew) + 4 * w, 0, 0));
       __syncthreads();
-    }
-    BTR_STAMP(c, 8);
-    if (tid == 0) {
-      const u32 skew = bytes_off & 3;
-      auto byte_at = [&](u32 o) -> u32 { return staged ? lds_raw[bytes_lds + skew + o] : base[bytes_off + o]; };
+      constexpr u32 kDead = 4096;  // offsets from here on map to themselves
+      auto jt = [&](u32 o) { return jump_lds + 2 * o; };
+#pragma unroll
+      for (u32 i = 0; i < 16; i++) {
+        const u32 o = i * kBlockThreads + tid;
+        u32 j = kDead + (o & 255);
+        if (o + 2 <= bytes_size) {
+          const u32 cex = lds_raw[bytes_lds + skew + o + 1];
+          j = o + 2 + (cex ? 1 + cex : 0);
+        }
+        *reinterpret_cast<u16*>(lds_raw + jt(o)) = (u16)j;
+      }
+      *reinterpret_cast<u16*>(lds_raw + jt(kDead + tid)) = (u16)(kDead + tid);
+      *reinterpret_cast<u16*>(lds_raw + jt(kDead + 256 + tid)) = (u16)(kDead + 256 + tid);
+      if (tid == 0) *reinterpret_cast<u16*>(lds_raw + pos_lds) = 0;
+      __syncthreads();
+      for (u32 t = 0; (1u << t) < blocks; t++) {
+        if (tid >= (1u << t) && tid < (2u << t) && tid < blocks)
+          *reinterpret_cast<u16*>(lds_raw + pos_lds + 2 * tid) = (u16)lds16(jt(lds16(pos_lds + 2 * (tid - (1u << t)))));
+        u32 nj[8];  // J_(t+1) of this thread's sixteen offsets, two per register
+#pragma unroll
+        for (u32 i = 0; i < 8; i++)
+          nj[i] = lds16(jt(lds16(jt(2 * i * kBlockThreads + tid)))) |
+                  (lds16(jt(lds16(jt((2 * i + 1) * kBlockThreads + tid)))) << 16);
+        __syncthreads();  // every thread has read J_t
+#pragma unroll
+        for (u32 i = 0; i < 8; i++) {
+          *reinterpret_cast<u16*>(lds_raw + jt(2 * i * kBlockThreads + tid)) = (u16)nj[i];
+          *reinterpret_cast<u16*>(lds_raw + jt((2 * i + 1) * kBlockThreads + tid)) = (u16)(nj[i] >> 16);
+        }
+        __syncthreads();
+      }
+      // one thread per block reads its record; the packs' first words are a prefix sum of 8 * b
+      u32 b = 0, cex = 0, k = 0, o = 0;
+      if (tid < blocks) {
+        o = lds16(pos_lds + 2 * tid);
+        if (o + 2 <= bytes_size) {
+          b = lds_raw[bytes_lds + skew + o];
+          cex = lds_raw[bytes_lds + skew + o + 1];
+          const u32 maxb = (cex && o + 3 <= bytes_size) ? lds_raw[bytes_lds + skew + o + 2] : 0u;
+          if (cex) {
+            if (maxb <= b || maxb > 32) bad = 1;
+            k = maxb > b ? maxb - b : 1;
+          }
+          if (o + 2 + (cex ? 1 + cex : 0) > bytes_size) bad = 1;
+        } else {
+          bad = 1;
+        }
+        if (b > 32) {
+          bad = 1;
+          b = 32;
+        }
+      }
+      u32 total;
+      const u32 before = block_exclusive_scan(c, tid < blocks ? 8 * b : 0u, &total);
+      if (tid < blocks) {
+        lds_st32(table_off + 16 * tid, b | (cex << 8) | (k << 16));
+        lds_st32(table_off + 16 * tid + 4, bytes_off + o + 2 + (cex ? 1 : 0));
+        lds_st32(table_off + 16 * tid + 12, data_word + before);
+      }
+    } else if (tid == 0) {
       u32 o = 0, dw = data_word;
       for (u32 r = 0; r < blocks; r++) {
         u32 b = 0, cex = 0, k = 0, maxb = 0;
         if (o + 3 <= bytes_size) {
-          b = byte_at(o);
-          cex = byte_at(o + 1);
-          maxb = byte_at(o + 2);
+          b = base[bytes_off + o];
+          cex = base[bytes_off + o + 1];
+          maxb = base[bytes_off + o + 2];
         } else if (o + 2 <= bytes_size) {
-          b = byte_at(o);
-          cex = byte_at(o + 1);
+          b = base[bytes_off + o];
+          cex = base[bytes_off + o + 1];
         } else {
           bad = 1;
         }
@@ -1913,28 +1973,43 @@ __device__ __forceinline__ void pfor_decode(const Ctx& c, const Step& s) {
       lds_st32(table_off + 16 * r + 8, before);
     }
     BTR_STAMP(c, 10);
-    // 3. the packed values of all blocks, consecutive rows on consecutive lanes; sixteen loads
-    //    in flight per lane
-    constexpr u32 kPforUnroll = 8;
-    for (u32 i0 = 0; i0 < len; i0 += kBlockThreads * kPforUnroll) {
-      u32 lo[kPforUnroll], hi[kPforUnroll], bw[kPforUnroll];
+    // 3. a wave per block: the block's packed words (at most 1 KiB) come into one of the wave's two
+    //    LDS copies by one direct-to-LDS load, the next block's load in flight meanwhile; lane l
+    //    extracts values l, l+64, l+128, l+192 and stores them
+    {
+      const u32 lane = tid & 63, wave = uniform(tid >> 6);
+      const u32 copies = packed_lds + 2048 * wave;
+      auto issue = [&](u32 r, u32 which) {
+        const u32 dw = uniform(lds32(table_off + 16 * r + 12));
+        const u32 words = 8 * (uniform(lds32(table_off + 16 * r)) & 0xFF) + 4;  // + the word an extraction reads ahead
+        if (4 * lane < words)  // only the lanes that cover the block fetch
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(lds_raw + copies + 1024 * which),
+                                                   16, (dw + 4 * lane) * 4, 0, 0, 0);
+      };
+      u32 which = 0;
+      if (wave < blocks) issue(wave, 0);
+      for (u32 r = wave; r < blocks; r += kBlockThreads / 64) {
+        const u32 rn = r + kBlockThreads / 64;
+        if (rn < blocks) {
+          issue(rn, which ^ 1);
+          asm volatile("s_waitcnt vmcnt(1)" ::: "memory");  // everything but the load just issued
+        } else {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        const u32 b = uniform(lds32(table_off + 16 * r)) & 0xFF;
+        const u32 copy = copies + 1024 * which;
+        u32 v[4];
 #pragma unroll
-      for (u32 q = 0; q < kPforUnroll; q++) {
-        const u32 i = i0 + q * kBlockThreads + tid;
-        const u32 r = (i < len ? i : len - 1) >> 8;
-        const u32 b = lds32(table_off + 16 * r) & 0xFF, dw = lds32(table_off + 16 * r + 12);
-        const u32 bit = ((i & 127) >> 2) * b;
-        const u32 w = dw + ((i >> 7) & 1) * 4 * b + 4 * (bit >> 5) + (i & 3);
-        lo[q] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, w * 4, 0, 0);
-        hi[q] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, (w + 4) * 4, 0, 0);
-        bw[q] = b | (bit << 8);
-      }
+        for (u32 q = 0; q < 4; q++) {
+          const u32 i = lane + 64 * q;
+          const u32 bit = ((i & 127) >> 2) * b;
+          const u32 a = copy + 4 * ((i >> 7) * 4 * b + 4 * (bit >> 5) + (i & 3));
+          const u32 x = __builtin_amdgcn_alignbit(lds32(a + 16), lds32(a), bit);
+          v[q] = b >= 32 ? x : (x & ((1u << b) - 1u));
+        }
 #pragma unroll
-      for (u32 q = 0; q < kPforUnroll; q++) {
-        const u32 i = i0 + q * kBlockThreads + tid;
-        const u32 b = bw[q] & 0xFF;
-        const u32 x = __builtin_amdgcn_alignbit(hi[q], lo[q], bw[q] >> 8);
-        if (i < len) tab_st32(out, first + i, b >= 32 ? x : (x & ((1u << b) - 1u)));
+        for (u32 q = 0; q < 4; q++) tab_st32(out, first + r * btrfmt::PFOR_BLOCK + lane + 64 * q, v[q]);
+        which ^= 1;
       }
     }
     __syncthreads();  // also orders the stores above before the patches below
@@ -2242,7 +2317,7 @@ btr_decode_int_kernel(const WorkItem* __restrict__ items, const u32* __restrict_
   decode_block<false>(items, order, programs, status);
 }
 
-extern "C" __global__ void __launch_bounds__(kBlockThreads)
+extern "C" __global__ void __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(5, 8)))
 btr_decode_dbl_kernel(const WorkItem* __restrict__ items, const u32* __restrict__ order,
                       const u8* __restrict__ programs, u32* __restrict__ status) {
   decode_block<true>(items, order, programs, status);

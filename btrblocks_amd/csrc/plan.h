@@ -165,11 +165,15 @@ constexpr uint32_t kStreamRingBytes = 16 * 1024;  // LDS ring of the streamed ro
 constexpr uint32_t kStreamProgBase = kStreamRingBytes + 16;
 // LDS scratch of one header-chain walker: a table of (1024 + 256) 16-bit jump pointers.
 constexpr uint32_t kWalkScratchBytes = (1024 + 256) * 2;
-// SIMDFastPFor page descriptor size and the LDS work area of S_PFOR_DECODE: a 16-byte entry per
-// 256-value block of a page (256 blocks), 1 KiB of staging per wave of the generic kernels, and
-// up to 1280 bytes of VariableByte tail (255 values of at most 5 bytes).
+// SIMDFastPFor page descriptor size and the LDS work area of S_PFOR_DECODE:
+//   [0, 4096)          a 16-byte entry per 256-value block of a page (256 blocks)
+//   [4096, 8192)       the page's byte container when it is at most 4 KiB
+//   [8192, 9472)       VariableByte tail (255 values of at most 5 bytes)
+//   [9472, 17664)      two 1 KiB copies of packed block data per wave of the generic kernels
+//   [17664, 26880)     jump pointers of the byte-container chain: u16[4096 + 512]
+//   [26880, 27392)     record offset per block: u16[256]
 constexpr uint32_t kPforPageWords = 5 + 31 + 31;
-constexpr uint32_t kPforWorkBytes = 4096 + 4096 + 1280;
+constexpr uint32_t kPforWorkBytes = 27392;
 // Streams with more groups than this get jump tables; shorter ones are walked without.
 constexpr uint32_t kWalkScratchMinGroups = 64;
 constexpr uint32_t kLdsCapBytes = 160 * 1024;  // all of a gfx950 CU's LDS; typical chunks need 5-40 KiB
