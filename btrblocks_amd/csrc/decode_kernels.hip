@@ -1846,7 +1846,7 @@ __device__ __forceinline__ void pfor_decode(const Ctx& c, const Step& s) {
   const Tab out = resolve_tab(c, uniform(s.a[4]));
   const u32 work = seq_lds(c, uniform(s.a[5]));
   const u32 table_off = work, bytes_lds = work + 4096, tail_off = work + 8192, packed_lds = work + 9472,
-            jump_lds = work + 17664, pos_lds = work + 26880;
+            jump_lds = packed_lds, pos_lds = packed_lds + 2 * (4096 + 512);  // dead before the rings fill
   const u32 n = out.count;
   const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(base, W * 4);
   u32 bad = 0;
@@ -1973,43 +1973,55 @@ __device__ __forceinline__ void pfor_decode(const Ctx& c, const Step& s) {
       lds_st32(table_off + 16 * r + 8, before);
     }
     BTR_STAMP(c, 10);
-    // 3. a wave per block: the block's packed words (at most 1 KiB) come into one of the wave's two
-    //    LDS copies by one direct-to-LDS load, the next block's load in flight meanwhile; lane l
-    //    extracts values l, l+64, l+128, l+192 and stores them
+    // 3. every wave takes a contiguous quarter of the blocks, whose packed words are contiguous
+    //    too, and streams them through its own 4 KiB LDS ring in 1 KiB pieces (one direct-to-LDS
+    //    load each, two pieces ahead): iteration p unpacks the blocks that start in piece p (they
+    //    may run into piece p+1, which has landed); lane l extracts values l, l+64, l+128, l+192.
     {
       const u32 lane = tid & 63, wave = uniform(tid >> 6);
-      const u32 copies = packed_lds + 2048 * wave;
-      auto issue = [&](u32 r, u32 which) {
-        const u32 dw = uniform(lds32(table_off + 16 * r + 12));
-        const u32 words = 8 * (uniform(lds32(table_off + 16 * r)) & 0xFF) + 4;  // + the word an extraction reads ahead
-        if (4 * lane < words)  // only the lanes that cover the block fetch
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(lds_raw + copies + 1024 * which),
-                                                   16, (dw + 4 * lane) * 4, 0, 0, 0);
-      };
-      u32 which = 0;
-      if (wave < blocks) issue(wave, 0);
-      for (u32 r = wave; r < blocks; r += kBlockThreads / 64) {
-        const u32 rn = r + kBlockThreads / 64;
-        if (rn < blocks) {
-          issue(rn, which ^ 1);
-          asm volatile("s_waitcnt vmcnt(1)" ::: "memory");  // everything but the load just issued
-        } else {
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        const u32 b = uniform(lds32(table_off + 16 * r)) & 0xFF;
-        const u32 copy = copies + 1024 * which;
-        u32 v[4];
+      constexpr u32 kWaves = kBlockThreads / 64, kPiece = 256, kRing = 4 * kPiece;
+      const u32 ring = packed_lds + 4 * kRing * wave;
+      const u32 r_begin = blocks * wave / kWaves, r_end = blocks * (wave + 1) / kWaves;
+      if (r_begin < r_end) {
+        const u32 w_lo = uniform(lds32(table_off + 16 * r_begin + 12));
+        const u32 last_e = uniform(lds32(table_off + 16 * (r_end - 1)));
+        const u32 w_hi = uniform(lds32(table_off + 16 * (r_end - 1) + 12)) + 8 * (last_e & 0xFF) + 4;
+        const u32 pieces = (w_hi - w_lo + kPiece - 1) / kPiece;
+        auto issue = [&](u32 piece) {
+          if (piece < pieces)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                rsrc, (__attribute__((address_space(3))) void*)(lds_raw + ring + 4 * kPiece * (piece & 3)), 16,
+                (w_lo + kPiece * piece + 4 * lane) * 4, 0, 0, 0);
+        };
+        issue(0);
+        issue(1);
+        u32 r = r_begin;
+        for (u32 piece = 0; piece < pieces && r < r_end; piece++) {
+          issue(piece + 2);  // its slot held piece - 2
+          // pieces <= piece + 1 have landed (and the stores of the previous iteration are out)
+          if (piece + 2 < pieces)
+            asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+          else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          while (r < r_end) {
+            const u32 rel = uniform(lds32(table_off + 16 * r + 12)) - w_lo;
+            if (rel >= kPiece * (piece + 1)) break;
+            const u32 b = uniform(lds32(table_off + 16 * r)) & 0xFF;
+            u32 v[4];
 #pragma unroll
-        for (u32 q = 0; q < 4; q++) {
-          const u32 i = lane + 64 * q;
-          const u32 bit = ((i & 127) >> 2) * b;
-          const u32 a = copy + 4 * ((i >> 7) * 4 * b + 4 * (bit >> 5) + (i & 3));
-          const u32 x = __builtin_amdgcn_alignbit(lds32(a + 16), lds32(a), bit);
-          v[q] = b >= 32 ? x : (x & ((1u << b) - 1u));
-        }
+            for (u32 q = 0; q < 4; q++) {
+              const u32 i = lane + 64 * q;
+              const u32 bit = ((i & 127) >> 2) * b;
+              const u32 w = rel + (i >> 7) * 4 * b + 4 * (bit >> 5) + (i & 3);
+              const u32 x = __builtin_amdgcn_alignbit(lds32(ring + 4 * ((w + 4) & (kRing - 1))),
+                                                      lds32(ring + 4 * (w & (kRing - 1))), bit);
+              v[q] = b >= 32 ? x : (x & ((1u << b) - 1u));
+            }
 #pragma unroll
-        for (u32 q = 0; q < 4; q++) tab_st32(out, first + r * btrfmt::PFOR_BLOCK + lane + 64 * q, v[q]);
-        which ^= 1;
+            for (u32 q = 0; q < 4; q++) tab_st32(out, first + r * btrfmt::PFOR_BLOCK + lane + 64 * q, v[q]);
+            r++;
+          }
+        }
       }
     }
     __syncthreads();  // also orders the stores above before the patches below

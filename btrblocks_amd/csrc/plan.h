@@ -169,11 +169,11 @@ constexpr uint32_t kWalkScratchBytes = (1024 + 256) * 2;
 //   [0, 4096)          a 16-byte entry per 256-value block of a page (256 blocks)
 //   [4096, 8192)       the page's byte container when it is at most 4 KiB
 //   [8192, 9472)       VariableByte tail (255 values of at most 5 bytes)
-//   [9472, 17664)      two 1 KiB copies of packed block data per wave of the generic kernels
-//   [17664, 26880)     jump pointers of the byte-container chain: u16[4096 + 512]
-//   [26880, 27392)     record offset per block: u16[256]
+//   [9472, 25856)      a 4 KiB ring of packed block data per wave of the generic kernels; before
+//                      the blocks are unpacked the same bytes hold the jump pointers of the
+//                      byte-container chain, u16[4096 + 512], and the record offset per block, u16[256]
 constexpr uint32_t kPforPageWords = 5 + 31 + 31;
-constexpr uint32_t kPforWorkBytes = 27392;
+constexpr uint32_t kPforWorkBytes = 25856;
 // Streams with more groups than this get jump tables; shorter ones are walked without.
 constexpr uint32_t kWalkScratchMinGroups = 64;
 constexpr uint32_t kLdsCapBytes = 160 * 1024;  // all of a gfx950 CU's LDS; typical chunks need 5-40 KiB
