@@ -557,20 +557,24 @@ btr_status btr_gpu_plan_stats(const btr_gpu_plan* plan, btr_plan_stats* out) {
   return BTR_OK;
 }
 
+using DecodeKernel = void (*)(const WorkItem*, const uint32_t*, const uint8_t*, uint32_t*);
+static DecodeKernel kernel_of(uint32_t kind) {
+  static const DecodeKernel kernels[KERNEL_KINDS] = {btr_decode_int_kernel,      btr_decode_dbl_kernel,
+                                                     btr_stream_none_kernel,     btr_stream_add_kernel,
+                                                     btr_stream_dict_lds_kernel, btr_stream_dict_glb_kernel,
+                                                     btr_stream_pseudo_kernel,   btr_stream_dictd_kernel};
+  return kernels[kind];
+}
+
 btr_status btr_gpu_decode(btr_gpu_ctx* ctx, btr_gpu_plan* plan, void* hip_stream) {
   if (!ctx || !plan) return fail(BTR_ERR_INVALID_ARGUMENT, "null argument");
   if (plan->n_items == 0) return BTR_OK;
   DeviceGuard guard(plan->device);
   if (!guard.ok) return fail(BTR_ERR_DEVICE, "hipSetDevice failed");
-  using Kernel = void (*)(const WorkItem*, const uint32_t*, const uint8_t*, uint32_t*);
-  static const Kernel kernels[KERNEL_KINDS] = {btr_decode_int_kernel,      btr_decode_dbl_kernel,
-                                               btr_stream_none_kernel,     btr_stream_add_kernel,
-                                               btr_stream_dict_lds_kernel, btr_stream_dict_glb_kernel,
-                                               btr_stream_pseudo_kernel,   btr_stream_dictd_kernel};
   for (uint32_t kind = 0; kind < KERNEL_KINDS; kind++) {
     const size_t n = plan->kind_begin[kind + 1] - plan->kind_begin[kind];
     if (n == 0) continue;
-    hipLaunchKernelGGL(kernels[kind], dim3((unsigned)n), dim3(kind >= KERNEL_STREAM_NONE ? kStreamThreads : kBlockThreads),
+    hipLaunchKernelGGL(kernel_of(kind), dim3((unsigned)n), dim3(kind >= KERNEL_STREAM_NONE ? kStreamThreads : kBlockThreads),
                        plan->kind_lds[kind],
                        (hipStream_t)hip_stream, plan->d_items, plan->d_order + plan->kind_begin[kind],
                        plan->d_programs, plan->d_status);
@@ -612,6 +616,15 @@ btr_status btr_gpu_plan_check(btr_gpu_ctx* ctx, btr_gpu_plan* plan, void* hip_st
     fprintf(stderr, "\n[btr debug] item start times (us), deciles:");
     for (int d = 0; d <= 10; d++) fprintf(stderr, " %.1f", starts[(starts.size() - 1) * d / 10] * 0.01);
     fprintf(stderr, "\n");
+    for (uint32_t kind = 0; kind < KERNEL_KINDS; kind++) {
+      if (plan->kind_begin[kind + 1] == plan->kind_begin[kind]) continue;
+      int per_cu = 0;
+      const int threads = kind >= KERNEL_STREAM_NONE ? kStreamThreads : kBlockThreads;
+      (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kernel_of(kind)), threads,
+                                                         plan->kind_lds[kind]);
+      fprintf(stderr, "[btr debug] %s: %u bytes of LDS, %d workgroups per CU\n", btr_kernel_name(kind),
+              plan->kind_lds[kind], per_cu);
+    }
   }
   uint32_t any = 0;
   uint64_t first = ~0ull;

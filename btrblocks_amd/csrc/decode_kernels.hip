@@ -31,6 +31,8 @@
 #include <stdint.h>
 
 #include "btr_format.h"
+#include <type_traits>
+
 #include "plan.h"
 
 using namespace btrplan;
@@ -1092,6 +1094,15 @@ __device__ __forceinline__ u32 ring_word(u32 w) {
   return lds32(RING | ((w << 2) & (kStreamRingBytes - 1)));
 }
 
+// Two consecutive words of ring 0 (which starts at LDS address 0) at byte offset a.
+__device__ __forceinline__ u32x2 ring_pair(u32 a) {
+  typedef __attribute__((address_space(3))) const u32 lds_word;
+  lds_word* p = (lds_word*)(__UINTPTR_TYPE__)a;
+  u32x2 r;
+  r.x = p[0], r.y = p[1];
+  return r;
+}
+
 // Batch t of a payload -> its ring slot, by direct-to-LDS loads (1 KiB per wave instruction).
 template <u32 RING>
 __device__ __forceinline__ void ring_issue(__amdgpu_buffer_rsrc_t rsrc, u32 t, u32 batches) {
@@ -1203,22 +1214,45 @@ __device__ __forceinline__ void ring_eval_groups(const StreamPost& sp, const Unp
 }
 
 // One batch of the header chain, read from the ring. Index entries are {first payload word, header}.
+// While groups are equally long the chain is followed by run steps on the ring itself: lane j reads
+// the word at pos + j*D (D = length of the group at pos) and the leading lanes that find the same
+// length there hold real headers. Only when a run breaks inside the batch are the lengths of all
+// 1024 words computed for the pointer-doubling walk.
 template <u32 RING = 0>
 __device__ __forceinline__ void ring_walk_batch(u32 index_off, u32 jump_off, u32 t, u32 groups, ChainState& st,
                                                 u32& bad_hdr) {
   const u32 lane = threadIdx.x & 63;
   const u32 bb = t * kBatchWords;
   const u32 slot = RING + (t & (kRingBatches - 1)) * (kBatchWords * 4);
+  auto glen = [](u32 x) {
+    const u32 s = 1 + __builtin_amdgcn_sad_u8(x, 0u, 0u);
+    return s > 255 ? 255u : s;
+  };
+  auto put = [&](u32 g, u32 hv, u32 position) {
+    if ((hv & 0xC0C0C0C0u) || ((hv + 0x5F5F5F5Fu) & 0x80808080u)) bad_hdr = 1;  // widths must be <= 32
+    lds_st64(index_off + 8 * g, ((u64)hv << 32) | (position + 1));
+  };
+  while (st.spec_ok && st.pos < bb + kBatchWords && st.g < groups) {
+    const u32 D = uniform(glen(ring_word<RING>(st.pos)));
+    const u32 pj = st.pos + lane * D;
+    const bool inside = pj < bb + kBatchWords;
+    const u32 hv = ring_word<RING>(inside ? pj : st.pos);
+    const u64 ok = __ballot(inside && glen(hv) == D);
+    u32 m = (u32)__builtin_ctzll(~ok | (1ull << 63));
+    m = m == 63 && (ok >> 63) ? 64 : m;
+    m = m < groups - st.g ? m : groups - st.g;
+    if (lane < m) put(st.g + lane, hv, pj);
+    st.g = uniform(st.g + m);
+    st.pos = uniform(st.pos + m * D);
+    if (m < 64 && st.pos < bb + kBatchWords) st.spec_ok = 0;  // the run broke inside the batch
+  }
+  if (!(st.pos < bb + kBatchWords && st.g < groups)) return;
   u32 d[kWalkBatch];
 #pragma unroll
   for (u32 k = 0; k < kWalkBatch; k++)
     d[k] = group_lengths(*reinterpret_cast<const u32x4*>(lds_raw + slot + k * 1024 + lane * 16));
   walk_chain(d, bb, groups, jump_off, st, [&](u32 first, u32 count, u32 position) {
-    if (lane < count) {
-      const u32 hv = ring_word<RING>(position);
-      if ((hv & 0xC0C0C0C0u) || ((hv + 0x5F5F5F5Fu) & 0x80808080u)) bad_hdr = 1;  // widths must be <= 32
-      lds_st64(index_off + 8 * (first + lane), ((u64)hv << 32) | (position + 1));
-    }
+    if (lane < count) put(first + lane, ring_word<RING>(position), position);
   });
 }
 
@@ -1228,28 +1262,31 @@ __device__ __forceinline__ void ring_walk_batch(u32 index_off, u32 jump_off, u32
 // found, [lo, hi) are the groups that start in batch t: their words are in the ring (a group that
 // starts in batch t may run into batch t+1, which has landed) and their index entries are written.
 // Ends with the walker's tail decode and a workgroup barrier.
-template <typename Publish, typename Unpack>
+template <bool KEEP_PREVIOUS = false, typename Publish, typename Unpack>
 __device__ __forceinline__ void ring_pass(const Ctx& c, const Pipe& p, const BpView& bp, u32 jump_off, Publish publish,
                                           Unpack unpack) {
   const u32 lane = threadIdx.x & 63, wave = uniform(threadIdx.x >> 6);
   const u32 W = uniform(p.a[1]), groups = uniform(p.a[5]);
   const u32 batches = (W + kBatchWords - 1) / kBatchWords;
   const u32 slot_off = c.red_off + 32;  // two LDS words: published value after batch t, slot t & 1
+  // KEEP_PREVIOUS: batch t-1 stays readable during iteration t (for unpackers that lag behind
+  // the walker), at the price of one batch less in flight.
+  constexpr u32 ahead = KEEP_PREVIOUS ? kRingAhead - 1 : kRingAhead;
 
   if (wave == kStreamWaves - 1) {
     // ---- loader
     const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(bp.base, bp.bytes);
-    for (u32 t = 0; t < kRingAhead; t++) ring_issue<0>(rsrc, t, batches);
+    for (u32 t = 0; t < ahead; t++) ring_issue<0>(rsrc, t, batches);
     // batches 0 and 1 landed (only batch 2 may still be in flight), then the start barrier
-    ring_wait(batches > 2);
+    ring_wait(!KEEP_PREVIOUS && batches > 2);
     ring_mirror<0>();
     __builtin_amdgcn_s_barrier();
     for (u32 t = 0; t < batches; t++) {
       // before barrier t: batch t+1 landed; at most batch t+2 stays in flight
-      ring_wait(t + 2 < batches);
+      ring_wait(!KEEP_PREVIOUS && t + 2 < batches);
       if (((t + 1) & (kRingBatches - 1)) == 0) ring_mirror<0>();
       __builtin_amdgcn_s_barrier();
-      ring_issue<0>(rsrc, t + kRingAhead, batches);  // its slot held batch t-1, fully consumed before this barrier
+      ring_issue<0>(rsrc, t + ahead, batches);  // its slot held batch t + ahead - 4, fully consumed before this barrier
     }
   } else if (wave == 0) {
     // ---- walker: batch 0 before barrier 0, then batch t+1 during iteration t
@@ -1410,14 +1447,28 @@ __device__ __forceinline__ void stream_exception_bits(const Ctx& c, const Pipe& 
       [&](u32 g_lo, u32 g_hi, u32 uw) {
         for (u32 G = g_lo + uw; G < g_hi; G += kUnpackWaves) {
           const u64 ee = lds64(be.index_off + 8 * G);
-          const u32 x0 = ring_extract<0>((u32)ee, (u32)(ee >> 32), u.sh_lo, u.pm_lo, u.k);
-          const u32 x1 = ring_extract<0>((u32)ee, (u32)(ee >> 32), u.sh_hi, u.pm_hi, u.k);
-          const u32 i0 = G * btrfmt::FBP_GROUP + lane, i1 = i0 + 64;
-          const u64 m0 = __ballot(i0 < be.rounded && x0 == btrfmt::DEC_EXCEPTION_CODE);
-          const u64 m1 = __ballot(i1 < be.rounded && x1 == btrfmt::DEC_EXCEPTION_CODE);
+          const u32 first = uniform((u32)ee), hdr = uniform((u32)(ee >> 32));
+          // The exception code needs five bits: a half whose two miniblocks are narrower has none.
+          // (Bits 3..7 of a width byte clear: width <= 7; then adding 3 sets bit 3 from width 5 on.)
+          const bool small = (hdr & 0xF8F8F8F8u) == 0;
+          const u32 wide = small ? (hdr + 0x03030303u) & 0x08080808u : 0x08080808u;
+          u64 m[2] = {0, 0};
+#pragma unroll
+          for (u32 h = 0; h < 2; h++) {
+            if ((wide & (h ? 0x00000808u : 0x08080000u)) == 0) continue;
+            const u32 b = __builtin_amdgcn_ubfe(hdr, h ? u.sh_hi : u.sh_lo, 8);
+            const u32 w = __builtin_amdgcn_sad_u8(hdr & (h ? u.pm_hi : u.pm_lo), 0u, first);
+            const u32 bit = __umul24(u.k, b);
+            const u32x2 pair = ring_pair(((w + (bit >> 5)) << 2) & (kStreamRingBytes - 1));
+            const u32 xa = __builtin_amdgcn_alignbit(pair.y, pair.x, bit);
+            // width 32 (small is false then): the whole word
+            const u32 x = small ? __builtin_amdgcn_ubfe(xa, 0u, b)
+                                : (__builtin_amdgcn_ubfe(xa, 0u, b) | (xa & (u32)__builtin_amdgcn_sbfe(b, 5, 1)));
+            m[h] = __builtin_amdgcn_ballot_w64(x == btrfmt::DEC_EXCEPTION_CODE);
+          }
           if (lane == 0) {
-            if (2 * G < words) lds_st64(rk.bits_off + 16 * G, m0);
-            if (2 * G + 1 < words) lds_st64(rk.bits_off + 16 * G + 8, m1);
+            if (2 * G < words) lds_st64(rk.bits_off + 16 * G, m[0]);
+            if (2 * G + 1 < words) lds_st64(rk.bits_off + 16 * G + 8, m[1]);
           }
         }
       });
@@ -1443,56 +1494,145 @@ __device__ __forceinline__ void stream_pseudo(const Ctx& c, const Pipe& root, co
   u32 exbad = 0;
   u32 row_end = 0;  // rows the pass could produce (walker wave only; shared through LDS below)
 
-  ring_pass(
+  u32 idx_max = 0;
+  const u32 groups_d = uniform(pd.a[5]);
+  // patch candidates are loaded through a descriptor: an index past the last patch reads 0
+  const __amdgpu_buffer_rsrc_t rsrc_p = make_rsrc(patches.g, patches.count * 8);
+  // rows lag up to one exponent group behind the digits: their words may sit in the previous batch
+  ring_pass<true>(
       c, pd, bd, jump_off,
       [&](const ChainState& st) {
-        // digits indexed so far -> rows that can be produced
+        // digits indexed so far -> rows that can be produced, in whole groups of the exponent stream
         const u32 digits_ready = st.g * btrfmt::FBP_GROUP < bd.rounded ? st.g * btrfmt::FBP_GROUP : bd.rounded;
         u32 r = select_clear(rk, words, n, digits_ready);
         r = r < be.rounded ? r : be.rounded;
+        r &= ~(btrfmt::FBP_GROUP - 1);
         row_end = r;
         return r;
       },
       [&](u32 r_lo, u32 r_hi, u32 uw) {
-        // rows [r_lo, r_hi) by 128-row groups of the exponent stream, two groups per iteration:
-        // their four exponent loads are in flight together
-        for (u32 G0 = (r_lo >> 7) + uw; G0 * btrfmt::FBP_GROUP < r_hi; G0 += 2 * kUnpackWaves) {
-          u32 x[2][2];
-#pragma unroll
-          for (u32 j = 0; j < 2; j++) {
-            const u32 G = G0 + j * kUnpackWaves;  // a group behind r_hi only yields dropped stores
-            const u64 ee = lds64(be.index_off + 8 * (G < groups_e ? G : G0));
-            x[j][0] = global_extract(rsrc_e, (u32)ee, (u32)(ee >> 32), u.sh_lo, u.pm_lo, u.k);
-            x[j][1] = global_extract(rsrc_e, (u32)ee, (u32)(ee >> 32), u.sh_hi, u.pm_hi, u.k);
-          }
+        // exponent groups [r_lo / 128, r_hi / 128), two per iteration, every lane four rows. A second
+        // group behind the end repeats the first one with dropped stores.
+        const u32 g_end = r_hi >> 7;
+        for (u32 G0 = (r_lo >> 7) + uw; G0 < g_end; G0 += 2 * kUnpackWaves) {
+          // Wave-uniform facts. The 128 rows of an exponent group use at most 128 consecutive
+          // digits, i.e. two digit groups, the first of them known from the rank in front of the
+          // group. Straight path: both digit groups packed with one width below 32 (the lane's
+          // digit then sits at a bit offset linear in its index) and all exponent widths <= 5
+          // (a value is a table index as it is).
+          u32 Gc[2], e_first[2], e_hdr[2], before[2][2], d_word[2], d_bw[2], d_rel[2], out_base[2];
+          // Loads first, in the order their addresses become known, so that the latencies overlap:
+          // exponent words (global), exception bits -> patch candidates (global), then the digits.
+          u32x2 ew[2][2], pw[2][2];
+          u32 eb[2][2], ebit[2][2], in[2][2];
 #pragma unroll
           for (u32 j = 0; j < 2; j++) {
             const u32 G = G0 + j * kUnpackWaves;
-            const u32 Gc = G < groups_e ? G : G0;
-            const u64 m0 = lds64(rk.bits_off + 16 * Gc), m1 = lds64(rk.bits_off + 16 * Gc + 8);
-            const u32 xr0 = __builtin_amdgcn_mbcnt_hi((u32)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((u32)m0, lds32(rk.rank_off + 8 * Gc)));
-            const u32 xr1 = __builtin_amdgcn_mbcnt_hi((u32)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((u32)m1, lds32(rk.rank_off + 8 * Gc + 4)));
-            const u32 i0 = G * btrfmt::FBP_GROUP + lane, i1 = i0 + 64;
-            u64 r[2];
+            Gc[j] = G < g_end ? G : G0;
+            out_base[j] = G < g_end ? G * (btrfmt::FBP_GROUP * 8) : 0x80000000u;  // out of range: dropped
+            const u64 ee = lds64(be.index_off + 8 * Gc[j]);
+            e_first[j] = uniform((u32)ee), e_hdr[j] = uniform((u32)(ee >> 32));
 #pragma unroll
             for (u32 h = 0; h < 2; h++) {
-              const u32 xv = x[j][h], xr = h ? xr1 : xr0, i = h ? i1 : i0;
-              const u32 di = i - xr;
-              const u64 ed = lds64(bd.index_off + 8 * (di >> 7));
-              const u32 m = (di >> 5) & 3;
-              const u32 dv = ring_extract<0>((u32)ed, (u32)(ed >> 32), 24 - 8 * m, ~(0xFFFFFFFFu >> (8 * m)), di & 31);
-              r[h] = pseudo_value(dv, xv, frac_off, exbad);
-              if (xv == btrfmt::DEC_EXCEPTION_CODE) r[h] = xr < patches.count ? ldg64(patches.g + 8ull * xr) : 0;
+              eb[j][h] = __builtin_amdgcn_ubfe(e_hdr[j], h ? u.sh_hi : u.sh_lo, 8);
+              const u32 w = __builtin_amdgcn_sad_u8(e_hdr[j] & (h ? u.pm_hi : u.pm_lo), 0u, e_first[j]);
+              ebit[j][h] = __umul24(u.k, eb[j][h]);
+              ew[j][h] = __builtin_amdgcn_raw_buffer_load_b64(rsrc_e, (w + (ebit[j][h] >> 5)) * 4, 0, 0);
             }
-            const u32 o0 = (i0 >= r_lo && i0 < r_hi) ? i0 * 8 : 0x80000000u;  // out of range: dropped
-            const u32 o1 = (i1 >= r_lo && i1 < r_hi) ? i1 * 8 : 0x80000000u;
-            u32x2 s0, s1;
-            s0.x = (u32)r[0], s0.y = (u32)(r[0] >> 32), s1.x = (u32)r[1], s1.y = (u32)(r[1] >> 32);
-            __builtin_amdgcn_raw_buffer_store_b64(s0, dst_rsrc, o0, 0, kStoreNt);
-            __builtin_amdgcn_raw_buffer_store_b64(s1, dst_rsrc, o1, 0, kStoreNt);
           }
+#pragma unroll
+          for (u32 j = 0; j < 2; j++) {
+            before[j][0] = uniform(lds32(rk.rank_off + 8 * Gc[j]));
+            before[j][1] = uniform(lds32(rk.rank_off + 8 * Gc[j] + 4));
+            const u64 m0 = lds64(rk.bits_off + 16 * Gc[j]), m1 = lds64(rk.bits_off + 16 * Gc[j] + 8);
+            // exceptions in front of this lane's rows inside their 64-row halves
+            in[j][0] = __builtin_amdgcn_mbcnt_hi((u32)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((u32)m0, 0u));
+            in[j][1] = __builtin_amdgcn_mbcnt_hi((u32)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((u32)m1, 0u));
+#pragma unroll
+            for (u32 h = 0; h < 2; h++)
+              pw[j][h] = __builtin_amdgcn_raw_buffer_load_b64(rsrc_p, (before[j][h] + in[j][h]) * 8, 0, 0);
+          }
+          bool straight = true;
+#pragma unroll
+          for (u32 j = 0; j < 2; j++) {
+            u32 gd = (Gc[j] * btrfmt::FBP_GROUP - before[j][0]) >> 7;
+            gd = gd < groups_d ? gd : groups_d - 1;
+            const u64 q0 = lds64(bd.index_off + 8 * gd), q1 = lds64(bd.index_off + 8 * gd + 8);
+            const u32 h0 = uniform((u32)(q0 >> 32)), h1 = uniform((u32)(q1 >> 32));
+            d_word[j] = uniform((u32)q0);
+            d_bw[j] = h0 & 0xFF;
+            d_rel[j] = (Gc[j] - gd) * btrfmt::FBP_GROUP;
+            straight = straight && (e_hdr[j] & 0xF8F8F8F8u) == 0 && ((e_hdr[j] + 0x02020202u) & 0xF8F8F8F8u) == 0 &&
+                       h0 == d_bw[j] * 0x01010101u && (h1 == h0 || gd + 1 >= groups_d) && d_bw[j] < 32;
+          }
+          auto rows = [&](auto tag) {
+            constexpr bool STRAIGHT = decltype(tag)::value;
+            u32 dlo[2][2], dhi[2][2], dbit[2][2], dwid[2][2], dfull[2][2];
+#pragma unroll
+            for (u32 j = 0; j < 2; j++)
+#pragma unroll
+              for (u32 h = 0; h < 2; h++) {
+                u32 a;
+                if (STRAIGHT) {
+                  const u32 rel = d_rel[j] + 64 * h - before[j][h] + lane - in[j][h];  // 0..255
+                  asm("v_mul_u32_u24_e32 %0, %1, %2" : "=v"(dbit[j][h]) : "s"(d_bw[j]), "v"(rel));
+                  a = ((d_word[j] + (dbit[j][h] >> 5) + (rel >> 7)) << 2) & (kStreamRingBytes - 1);
+                  dwid[j][h] = d_bw[j];
+                  dfull[j][h] = 0;
+                } else {
+                  const u32 di = Gc[j] * btrfmt::FBP_GROUP + 64 * h + lane - before[j][h] - in[j][h];
+                  const u64 ed = lds64(bd.index_off + 8 * (di >> 7));
+                  const u32 m = (di >> 5) & 3;
+                  const u32 hdr = (u32)(ed >> 32);
+                  dwid[j][h] = __builtin_amdgcn_ubfe(hdr, 24 - 8 * m, 8);
+                  const u32 w = __builtin_amdgcn_sad_u8(hdr & ~(0xFFFFFFFFu >> (8 * m)), 0u, (u32)ed);
+                  dbit[j][h] = __umul24(di & 31, dwid[j][h]);
+                  a = ((w + (dbit[j][h] >> 5)) << 2) & (kStreamRingBytes - 1);
+                  dfull[j][h] = (u32)__builtin_amdgcn_sbfe(dwid[j][h], 5, 1);  // all ones for width 32
+                }
+                const u32x2 pair = ring_pair(a);
+                dlo[j][h] = pair.x, dhi[j][h] = pair.y;
+              }
+            u32 xv[2][2];
+            u64 fr[2][2];
+#pragma unroll
+            for (u32 j = 0; j < 2; j++)
+#pragma unroll
+              for (u32 h = 0; h < 2; h++) {
+                const u32 xa = __builtin_amdgcn_alignbit(ew[j][h].y, ew[j][h].x, ebit[j][h]);
+                xv[j][h] = __builtin_amdgcn_ubfe(xa, 0u, eb[j][h]);
+                if (!STRAIGHT) xv[j][h] |= xa & (u32)__builtin_amdgcn_sbfe(eb[j][h], 5, 1);  // width 32
+                const u32 idx = STRAIGHT ? xv[j][h] : xv[j][h] & btrfmt::DEC_INDEX_MASK;
+                idx_max = idx_max > idx ? idx_max : idx;
+                // an exponent that is neither the exception code nor a table index: reported
+                if (!STRAIGHT && idx == btrfmt::DEC_EXCEPTION_CODE && xv[j][h] != btrfmt::DEC_EXCEPTION_CODE) exbad |= 2;
+                fr[j][h] = lds64(frac_off + 8 * idx);
+              }
+#pragma unroll
+            for (u32 j = 0; j < 2; j++) {
+              u32x2 out[2];
+#pragma unroll
+              for (u32 h = 0; h < 2; h++) {
+                const u32 da = __builtin_amdgcn_alignbit(dhi[j][h], dlo[j][h], dbit[j][h]);
+                u32 dv = __builtin_amdgcn_ubfe(da, 0u, dwid[j][h]);
+                if (!STRAIGHT) dv |= da & dfull[j][h];
+                const u64 r = (u64)__double_as_longlong((double)(int)dv * __longlong_as_double((long long)fr[j][h]));
+                const bool patch = xv[j][h] == btrfmt::DEC_EXCEPTION_CODE;
+                out[h].x = patch ? pw[j][h].x : (u32)r;
+                out[h].y = patch ? pw[j][h].y : (u32)(r >> 32);
+              }
+              const u32 o = out_base[j] + lane * 8;
+              __builtin_amdgcn_raw_buffer_store_b64(out[0], dst_rsrc, o, 0, kStoreNt);
+              __builtin_amdgcn_raw_buffer_store_b64(out[1], dst_rsrc, o + 512, 0, kStoreNt);
+            }
+          };
+          if (straight)
+            rows(std::true_type{});
+          else
+            rows(std::false_type{});
         }
       });
+  if (idx_max > btrfmt::DEC_EXCEPTION_CODE) exbad |= 2;
   // rows behind the last one the pass could produce: digits or exponents from the tails
   const u32 end_off = c.red_off + 32;
   if (threadIdx.x == 0) lds_st32(end_off, row_end);
@@ -2267,7 +2407,8 @@ __device__ __forceinline__ void stream_pseudo_block(const WorkItem* __restrict__
   rk.bits_off = seq_lds(c, uniform(rp.a[3]));
   rk.rank_off = seq_lds(c, uniform(rp.a[4]));
   const u32 n = uniform(rp.count);
-  if (threadIdx.x < 23) lds_st64(frac_off + 8 * threadIdx.x, (u64)__double_as_longlong(kFractions[threadIdx.x]));
+  if (threadIdx.x < 32)  // indexed by exponent & 31: entries above the largest exponent repeat it
+    lds_st64(frac_off + 8 * threadIdx.x, (u64)__double_as_longlong(kFractions[threadIdx.x < 22 ? threadIdx.x : 22]));
   bitmap_clear<kStreamThreads>(c, step_at(c, 0));
   __syncthreads();
   stamp(it, 2);
@@ -2357,7 +2498,7 @@ btr_stream_dict_glb_kernel(const WorkItem* __restrict__ items, const u32* __rest
   stream_block<PS_DICT_GLB>(items, order, programs, status);
 }
 // PSEUDODECIMAL(BP, BP, raw patches) double columns (plan.h: KERNEL_STREAM_PSEUDO).
-extern "C" __global__ void __launch_bounds__(kStreamThreads)
+extern "C" __global__ void __launch_bounds__(kStreamThreads) __attribute__((amdgpu_waves_per_eu(8, 8)))
 btr_stream_pseudo_kernel(const WorkItem* __restrict__ items, const u32* __restrict__ order,
                          const u8* __restrict__ programs, u32* __restrict__ status) {
   stream_pseudo_block(items, order, programs, status);
