@@ -557,6 +557,9 @@ btr_status btr_gpu_plan_stats(const btr_gpu_plan* plan, btr_plan_stats* out) {
   return BTR_OK;
 }
 
+static unsigned threads_of(uint32_t kind) {
+  return kind == KERNEL_STREAM_DICTD ? kDictdThreads : kind >= KERNEL_STREAM_NONE ? kStreamThreads : kBlockThreads;
+}
 using DecodeKernel = void (*)(const WorkItem*, const uint32_t*, const uint8_t*, uint32_t*);
 static DecodeKernel kernel_of(uint32_t kind) {
   static const DecodeKernel kernels[KERNEL_KINDS] = {btr_decode_int_kernel,      btr_decode_dbl_kernel,
@@ -574,7 +577,7 @@ btr_status btr_gpu_decode(btr_gpu_ctx* ctx, btr_gpu_plan* plan, void* hip_stream
   for (uint32_t kind = 0; kind < KERNEL_KINDS; kind++) {
     const size_t n = plan->kind_begin[kind + 1] - plan->kind_begin[kind];
     if (n == 0) continue;
-    hipLaunchKernelGGL(kernel_of(kind), dim3((unsigned)n), dim3(kind >= KERNEL_STREAM_NONE ? kStreamThreads : kBlockThreads),
+    hipLaunchKernelGGL(kernel_of(kind), dim3((unsigned)n), dim3(threads_of(kind)),
                        plan->kind_lds[kind],
                        (hipStream_t)hip_stream, plan->d_items, plan->d_order + plan->kind_begin[kind],
                        plan->d_programs, plan->d_status);
@@ -614,12 +617,12 @@ btr_status btr_gpu_plan_check(btr_gpu_ctx* ctx, btr_gpu_plan* plan, void* hip_st
       if (ts[i * kDebugSlots]) starts.push_back(ts[i * kDebugSlots] - t0);
     std::sort(starts.begin(), starts.end());
     fprintf(stderr, "\n[btr debug] item start times (us), deciles:");
-    for (int d = 0; d <= 10; d++) fprintf(stderr, " %.1f", starts[(starts.size() - 1) * d / 10] * 0.01);
+    for (int d = 0; d <= 10 && !starts.empty(); d++) fprintf(stderr, " %.1f", starts[(starts.size() - 1) * d / 10] * 0.01);
     fprintf(stderr, "\n");
     for (uint32_t kind = 0; kind < KERNEL_KINDS; kind++) {
       if (plan->kind_begin[kind + 1] == plan->kind_begin[kind]) continue;
       int per_cu = 0;
-      const int threads = kind >= KERNEL_STREAM_NONE ? kStreamThreads : kBlockThreads;
+      const int threads = (int)threads_of(kind);
       (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kernel_of(kind)), threads,
                                                          plan->kind_lds[kind]);
       fprintf(stderr, "[btr debug] %s: %u bytes of LDS, %d workgroups per CU\n", btr_kernel_name(kind),

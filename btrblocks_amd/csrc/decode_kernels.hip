@@ -146,6 +146,12 @@ __device__ __forceinline__ void stamp(const WorkItem& it, u32 slot) {
 }
 __device__ __forceinline__ u32 seq_lds(const Ctx& c, u32 seq_id) { return c.table_base + uniform(seq_at(c, seq_id).off); }
 
+// LDS offset of a streamed root's jump-table scratch, or NONE when the plan gave it up.
+__device__ __forceinline__ u32 jump_scratch(const Ctx& c, const Step& root) {
+  const u32 seq = uniform(root.a[3]);
+  return seq == NONE ? NONE : seq_lds(c, seq);
+}
+
 // A resolved sequence: LDS byte offset or global pointer.
 struct Tab {
   const u8* g;  // global base (scratch, source bytes or output); unused for LDS
@@ -1075,6 +1081,10 @@ __device__ __forceinline__ void mat_int_bp(const Ctx& c, const IntEval& e, const
 constexpr u32 kStreamThreads = 512;
 constexpr u32 kStreamWaves = kStreamThreads / 64;
 constexpr u32 kUnpackWaves = kStreamWaves - 2;
+// The double-dictionary kernel keeps up to 32 KiB of dictionary in LDS, so few of its workgroups
+// fit a CU: it runs 16 waves per workgroup (14 unpackers) to fill the CU with two of them.
+constexpr u32 kDictdThreads = 1024;
+constexpr u32 kDictdWaves = kDictdThreads / 64;
 constexpr u32 kRingBatches = 4;  // power of two
 constexpr u32 kRingAhead = 3;    // batches issued ahead of the one being unpacked
 constexpr u32 kRingWords = kRingBatches * kBatchWords;
@@ -1262,7 +1272,7 @@ __device__ __forceinline__ void ring_walk_batch(u32 index_off, u32 jump_off, u32
 // found, [lo, hi) are the groups that start in batch t: their words are in the ring (a group that
 // starts in batch t may run into batch t+1, which has landed) and their index entries are written.
 // Ends with the walker's tail decode and a workgroup barrier.
-template <bool KEEP_PREVIOUS = false, typename Publish, typename Unpack>
+template <bool KEEP_PREVIOUS = false, u32 WAVES = kStreamWaves, typename Publish, typename Unpack>
 __device__ __forceinline__ void ring_pass(const Ctx& c, const Pipe& p, const BpView& bp, u32 jump_off, Publish publish,
                                           Unpack unpack) {
   const u32 lane = threadIdx.x & 63, wave = uniform(threadIdx.x >> 6);
@@ -1273,7 +1283,7 @@ __device__ __forceinline__ void ring_pass(const Ctx& c, const Pipe& p, const BpV
   // the walker), at the price of one batch less in flight.
   constexpr u32 ahead = KEEP_PREVIOUS ? kRingAhead - 1 : kRingAhead;
 
-  if (wave == kStreamWaves - 1) {
+  if (wave == WAVES - 1) {
     // ---- loader
     const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(bp.base, bp.bytes);
     for (u32 t = 0; t < ahead; t++) ring_issue<0>(rsrc, t, batches);
@@ -1365,10 +1375,10 @@ __device__ __forceinline__ void stream_dictd(const Ctx& c, const Pipe& root, u64
     code = code < dict.count ? code : dict.count - 1;
     return in_lds ? lds64(dict.lds + 8 * code) : ldg64(dict.g + 8ull * code);
   };
-  ring_pass(
+  ring_pass<false, kDictdWaves>(
       c, pc, bp, jump_off, [](const ChainState& st) { return st.g; },
       [&](u32 g_lo, u32 g_hi, u32 uw) {
-        for (u32 g = g_lo + uw; g < g_hi; g += kUnpackWaves) {
+        for (u32 g = g_lo + uw; g < g_hi; g += kDictdWaves - 2) {
           const u64 en = lds64(bp.index_off + 8 * g);
           const u32 c0 = ring_extract<0>((u32)en, (u32)(en >> 32), u.sh_lo, u.pm_lo, u.k);
           const u32 c1 = ring_extract<0>((u32)en, (u32)(en >> 32), u.sh_hi, u.pm_hi, u.k);
@@ -1380,7 +1390,7 @@ __device__ __forceinline__ void stream_dictd(const Ctx& c, const Pipe& root, u64
           __builtin_amdgcn_raw_buffer_store_b64(s1, dst_rsrc, o + 512, 0, kStoreNt);
         }
       });
-  for (u32 i = bp.rounded + threadIdx.x; i < n; i += kStreamThreads)
+  for (u32 i = bp.rounded + threadIdx.x; i < n; i += kDictdThreads)
     dst[i] = gather(lds32(bp.tail_off + 4 * ((i - bp.rounded) & 31)));
   if (code_max >= dict.count) raise(c, ST_DICT_CODE);
 }
@@ -2346,6 +2356,27 @@ __device__ __forceinline__ ProgramHeader load_program(const WorkItem& it, u32 it
   return hdr;
 }
 
+// bytes (a multiple of 4) from global memory (any alignment) to LDS (16-byte aligned) by the
+// THREADS threads of a stream kernel: four 16-byte pieces in flight per thread.
+template <u32 THREADS>
+__device__ __forceinline__ void copy_to_lds(u32 lds_off, const u8* __restrict__ g, u32 bytes) {
+  const u32 pieces = bytes / 16;
+  for (u32 i0 = 0; i0 < pieces; i0 += 4 * THREADS) {
+    u32x4 v[4];
+#pragma unroll
+    for (u32 k = 0; k < 4; k++) {
+      const u32 i = i0 + k * THREADS + threadIdx.x;
+      if (i < pieces) __builtin_memcpy(&v[k], g + 16ull * i, 16);
+    }
+#pragma unroll
+    for (u32 k = 0; k < 4; k++) {
+      const u32 i = i0 + k * THREADS + threadIdx.x;
+      if (i < pieces) *reinterpret_cast<u32x4*>(lds_raw + lds_off + 16 * i) = v[k];
+    }
+  }
+  for (u32 o = pieces * 16 + 4 * threadIdx.x; o < bytes; o += 4 * THREADS) lds_st32(lds_off + o, ldg32(g + o));
+}
+
 // Lean kernel body for chunks whose program is [optional dictionary copy into LDS] + streamed
 // bit-packed root: DICT(BP), FOR(BP) and plain BP integer columns.
 template <u32 PS>
@@ -2359,14 +2390,13 @@ __device__ __forceinline__ void stream_block(const WorkItem* __restrict__ items,
     const Step& st = step_at(c, s);
     const Tab from = resolve_tab(c, uniform(pipe_at(c, uniform(st.a[0])).a[0]));
     const Tab to = resolve_tab(c, uniform(st.a[1]));
-    for (u32 i = threadIdx.x; i < to.count * (to.esize / 4); i += kStreamThreads)
-      lds_st32(to.lds + 4 * i, ldg32(from.g + 4ull * i));
+    copy_to_lds<kStreamThreads>(to.lds, from.g, to.count * to.esize);
   }
   __syncthreads();
   const Step& root = step_at(c, hdr.n_steps - 1);
   const u32 pipe_id = uniform(root.a[0]);
   const IntEval e = resolve_int(c, pipe_id);
-  stream_int_bp<PS>(c, pipe_at(c, pipe_id), e, reinterpret_cast<u32*>(c.dst), seq_lds(c, uniform(root.a[3])));
+  stream_int_bp<PS>(c, pipe_at(c, pipe_id), e, reinterpret_cast<u32*>(c.dst), jump_scratch(c, root));
 }
 
 // DICT(BP) double chunks: [dictionary copy into LDS] + streamed root.
@@ -2375,17 +2405,19 @@ __device__ __forceinline__ void stream_dictd_block(const WorkItem* __restrict__ 
   const u32 item = order[blockIdx.x];
   const WorkItem it = items[item];
   Ctx c;
-  const ProgramHeader hdr = load_program<kStreamThreads, kStreamProgBase>(it, item, programs, status, c);
+  stamp(it, 0);
+  const ProgramHeader hdr = load_program<kDictdThreads, kStreamProgBase>(it, item, programs, status, c);
   for (u32 s = 0; s + 1 < hdr.n_steps; s++) {
     const Step& st = step_at(c, s);
     const Tab from = resolve_tab(c, uniform(pipe_at(c, uniform(st.a[0])).a[0]));
     const Tab to = resolve_tab(c, uniform(st.a[1]));
-    for (u32 i = threadIdx.x; i < to.count * (to.esize / 4); i += kStreamThreads)
-      lds_st32(to.lds + 4 * i, ldg32(from.g + 4ull * i));
+    copy_to_lds<kDictdThreads>(to.lds, from.g, to.count * to.esize);
   }
   __syncthreads();
+  stamp(it, 1);
   const Step& root = step_at(c, hdr.n_steps - 1);
-  stream_dictd(c, pipe_at(c, uniform(root.a[0])), reinterpret_cast<u64*>(c.dst), seq_lds(c, uniform(root.a[3])));
+  stream_dictd(c, pipe_at(c, uniform(root.a[0])), reinterpret_cast<u64*>(c.dst), jump_scratch(c, root));
+  stamp(it, 2);
 }
 
 // PSEUDODECIMAL(BP, BP, raw patches) chunks. The program is [clear bitmap, rank, streamed root]:
@@ -2402,7 +2434,7 @@ __device__ __forceinline__ void stream_pseudo_block(const WorkItem* __restrict__
   const Pipe& rp = pipe_at(c, uniform(root.a[0]));
   const Pipe& pd = pipe_at(c, uniform(rp.a[0]));
   const Pipe& pe = pipe_at(c, uniform(rp.a[1]));
-  const u32 frac_off = seq_lds(c, uniform(root.a[2])), jump_off = seq_lds(c, uniform(root.a[3]));
+  const u32 frac_off = seq_lds(c, uniform(root.a[2])), jump_off = jump_scratch(c, root);
   RankView rk;
   rk.bits_off = seq_lds(c, uniform(rp.a[3]));
   rk.rank_off = seq_lds(c, uniform(rp.a[4]));
@@ -2504,7 +2536,7 @@ btr_stream_pseudo_kernel(const WorkItem* __restrict__ items, const u32* __restri
   stream_pseudo_block(items, order, programs, status);
 }
 // DICT(BP) double columns (plan.h: KERNEL_STREAM_DICTD).
-extern "C" __global__ void __launch_bounds__(kStreamThreads)
+extern "C" __global__ void __launch_bounds__(kDictdThreads)
 btr_stream_dictd_kernel(const WorkItem* __restrict__ items, const u32* __restrict__ order,
                         const u8* __restrict__ programs, u32* __restrict__ status) {
   stream_dictd_block(items, order, programs, status);

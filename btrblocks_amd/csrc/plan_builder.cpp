@@ -658,51 +658,87 @@ void build_program(const ColumnSource& src, BuiltProgram& out) {
                             bld.seqs.size() * sizeof(Seq) + bld.consts.size() * 4;
   const uint32_t table_base = prog_base + align_up((uint32_t)prog_bytes, 16) + 64;  // + reduction scratch
   uint64_t lds = 0, scratch = 0;
-  for (auto& s : bld.seqs)
-    if (s.loc == LOC_LDS && s.must_lds) {
-      s.off = (uint32_t)lds;
-      lds += align_up(s.count * s.esize, 16);
-    }
-  if (table_base + lds > kLdsCapBytes && kernel <= KERNEL_GENERIC_DBL) {
-    // very large blocks: give up the walkers' jump tables (they only speed the index steps up)
-    for (uint32_t k = 0; k < 4; k++)
-      if (walk_scratch[k] != NONE) {
-        lds -= align_up(bld.seqs[walk_scratch[k]].count * bld.seqs[walk_scratch[k]].esize, 16);
-        bld.seqs[walk_scratch[k]].count = 0;
-      }
-    for (Step& st : bld.bp_steps) st.a[1] = NONE;
-    lds = 0;
+  auto place_tables = [&]() {
+    lds = scratch = 0;
     for (auto& s : bld.seqs)
       if (s.loc == LOC_LDS && s.must_lds) {
         s.off = (uint32_t)lds;
         lds += align_up(s.count * s.esize, 16);
       }
-  }
-  {
-    // one shared region for the transient tables, sized for the largest
-    uint64_t shared = 0;
-    for (uint32_t id : bld.transient) shared = std::max<uint64_t>(shared, align_up(bld.seqs[id].count * bld.seqs[id].esize, 16));
-    const uint32_t cap = kernel <= KERNEL_GENERIC_DBL ? kLdsSoftCapGeneric : kLdsSoftCapStream;
-    if (shared && table_base + lds + shared <= cap) {
-      for (uint32_t id : bld.transient) {
-        bld.seqs[id].off = (uint32_t)lds;
-        bld.seqs[id].must_lds = 2;  // placed
+    if (table_base + lds > kLdsCapBytes && kernel <= KERNEL_GENERIC_DBL) {
+      // very large blocks: give up the walkers' jump tables (they only speed the index steps up)
+      for (uint32_t k = 0; k < 4; k++)
+        if (walk_scratch[k] != NONE) {
+          lds -= align_up(bld.seqs[walk_scratch[k]].count * bld.seqs[walk_scratch[k]].esize, 16);
+          bld.seqs[walk_scratch[k]].count = 0;
+        }
+      for (Step& st : bld.bp_steps) st.a[1] = NONE;
+      lds = 0;
+      for (auto& s : bld.seqs)
+        if (s.loc == LOC_LDS && s.must_lds) {
+          s.off = (uint32_t)lds;
+          lds += align_up(s.count * s.esize, 16);
+        }
+    }
+    {
+      // one shared region for the transient tables, sized for the largest
+      uint64_t shared = 0;
+      for (uint32_t id : bld.transient) shared = std::max<uint64_t>(shared, align_up(bld.seqs[id].count * bld.seqs[id].esize, 16));
+      const uint32_t cap = kernel <= KERNEL_GENERIC_DBL ? kLdsSoftCapGeneric : kLdsSoftCapStream;
+      if (shared && table_base + lds + shared <= cap) {
+        for (uint32_t id : bld.transient) {
+          bld.seqs[id].off = (uint32_t)lds;
+          bld.seqs[id].must_lds = 2;  // placed
+        }
+        lds += shared;
       }
-      lds += shared;
+    }
+    for (auto& s : bld.seqs)
+      if (s.loc == LOC_LDS && !s.must_lds) {
+        const uint64_t bytes = align_up(s.count * s.esize, 16);
+        if (table_base + lds + bytes <= (kernel <= KERNEL_GENERIC_DBL ? kLdsSoftCapGeneric : kLdsSoftCapStream)) {
+          s.off = (uint32_t)lds;
+          lds += bytes;
+        } else {
+          s.loc = LOC_SCRATCH;
+          s.off = (uint32_t)scratch;
+          scratch += bytes;
+        }
+      }
+  };
+  const std::vector<Seq> unplaced = bld.seqs;
+  place_tables();
+  if (kernel >= KERNEL_STREAM_NONE && kernel != KERNEL_STREAM_PSEUDO && bld.steps.back().a[3] != NONE) {
+    // A stream kernel runs at most four 512-thread workgroups per CU, fewer when LDS runs out. The
+    // walker's jump table only speeds up streams whose group lengths vary: when all groups of this
+    // stream are equally long, give it up if that lets one more workgroup share the CU.
+    // (the double-dictionary kernel runs 1024-thread workgroups: two per CU at most)
+    const uint64_t most = kernel == KERNEL_STREAM_DICTD ? 2 : 4;
+    auto per_cu = [&](uint64_t bytes) { return std::min<uint64_t>(most, kLdsCapBytes / bytes); };
+    const uint64_t with = table_base + lds, without = with - align_up(kWalkScratchBytes, 16);
+    const Pipe& bp = kernel == KERNEL_STREAM_DICTD ? bld.pipes[bld.pipes[root].a[0]] : bld.pipes[root];
+    auto equally_long = [&]() {
+      const uint8_t* words = src.host + bp.a[0];
+      const uint64_t W = bp.a[1];
+      uint64_t pos = 1, first_len = 0;  // word 0 is the value count
+      for (uint32_t g = 0; g + 1 < bp.a[5]; g++) {  // the length of the last group ends no step
+        if (pos >= W) return false;
+        const uint8_t* h = words + 4 * pos;
+        const uint64_t len = 1 + h[0] + h[1] + h[2] + h[3];
+        if (g == 0) first_len = len;
+        if (len != first_len) return false;
+        pos += len;
+      }
+      return true;
+    };
+    if (per_cu(without) > per_cu(with) && equally_long()) {
+      const uint32_t jump = bld.steps.back().a[3];
+      bld.seqs = unplaced;
+      bld.seqs[jump].count = 0;
+      bld.steps.back().a[3] = NONE;
+      place_tables();
     }
   }
-  for (auto& s : bld.seqs)
-    if (s.loc == LOC_LDS && !s.must_lds) {
-      const uint64_t bytes = align_up(s.count * s.esize, 16);
-      if (table_base + lds + bytes <= (kernel <= KERNEL_GENERIC_DBL ? kLdsSoftCapGeneric : kLdsSoftCapStream)) {
-        s.off = (uint32_t)lds;
-        lds += bytes;
-      } else {
-        s.loc = LOC_SCRATCH;
-        s.off = (uint32_t)scratch;
-        scratch += bytes;
-      }
-    }
   if (table_base + lds > kLdsCapBytes)
     throw PlanError(ST_UNSUPPORTED, "decode tables of this chunk exceed the LDS budget (" +
                                         std::to_string(table_base + lds) + " bytes)");
