@@ -442,6 +442,7 @@ struct DblEval {
   Tab tab;      // B_SEQ / B_RLE values / B_FREQ exceptions / B_DICTD dictionary / B_PSEUDO patches
   IntEval ia;   // B_DICTD codes / B_PSEUDO digits / B_DBP word stream
   IntEval ib;   // B_PSEUDO exponents
+  u32 frac_lo, frac_hi;  // B_PSEUDO: lane l holds 10^-min(l, 22), fetched per row by a lane permute
 };
 
 __device__ __forceinline__ DblEval resolve_dbl(const Ctx& c, u32 pipe_id) {
@@ -454,6 +455,7 @@ __device__ __forceinline__ DblEval resolve_dbl(const Ctx& c, u32 pipe_id) {
   e.tab = resolve_tab(c, NONE);
   e.ia.base = e.ib.base = B_ONE;
   e.ia.n_post = e.ib.n_post = 0;
+  e.frac_lo = e.frac_hi = 0;
   const u32 a0 = uniform(p.a[0]), a1 = uniform(p.a[1]), a2 = uniform(p.a[2]), a3 = uniform(p.a[3]),
             a4 = uniform(p.a[4]), a5 = uniform(p.a[5]);
   switch (e.base) {
@@ -485,6 +487,11 @@ __device__ __forceinline__ DblEval resolve_dbl(const Ctx& c, u32 pipe_id) {
       e.rk.bits_off = seq_lds(c, a3);
       e.rk.rank_off = seq_lds(c, a4);
       e.k0 = a5;
+      {
+        const u32 l = threadIdx.x & 63;
+        const u64 f = (u64)__double_as_longlong(kFractions[l < btrfmt::DEC_MAX_EXPONENT ? l : btrfmt::DEC_MAX_EXPONENT]);
+        e.frac_lo = (u32)f, e.frac_hi = (u32)(f >> 32);
+      }
       break;
     case B_DBP:
       e.ia.base = B_BP;
@@ -536,7 +543,9 @@ __device__ __forceinline__ u64 eval_dbl(const DblEval& e, u32 i, u32& bad) {
     u32 idx = ex & btrfmt::DEC_INDEX_MASK;
     bad |= (ex != btrfmt::DEC_EXCEPTION_CODE && idx > btrfmt::DEC_MAX_EXPONENT) ? 2u : 0u;
     idx = idx > btrfmt::DEC_MAX_EXPONENT ? btrfmt::DEC_MAX_EXPONENT : idx;
-    u64 r = (u64)__double_as_longlong((double)digits * kFractions[idx]);
+    const u64 fbits = ((u64)(u32)__builtin_amdgcn_ds_bpermute(idx << 2, e.frac_hi) << 32) |
+                      (u32)__builtin_amdgcn_ds_bpermute(idx << 2, e.frac_lo);
+    u64 r = (u64)__double_as_longlong((double)digits * __longlong_as_double((long long)fbits));
     if (ex == btrfmt::DEC_EXCEPTION_CODE) {
       const u32 pi = xr < e.tab.count ? xr : e.tab.count - 1;
       r = e.tab.count ? tab_ld64(e.tab, pi) : 0;
