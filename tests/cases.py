@@ -51,6 +51,13 @@ def cases():
     add("int_depth5_for_chain", synth.int_for(N), "for(for(for(bp)))", max_cascade_depth=5)
     add("int_example_auto", synth.example_runs(65000), "auto")
     add("int_auto_random", _rng(17).integers(0, 100000, N).astype(np.int32), "auto")
+    # dictionaries around the size where the plan trades the walker's jump table for one more
+    # workgroup per CU: equally wide code groups (table given up) and varying ones (table kept)
+    pool = _rng(40).integers(-2**31, 2**31, 4400).astype(np.int32)
+    even = _rng(41).integers(0, 4400, N)
+    even[::32] = np.argsort(pool)[-1]  # every miniblock holds the largest code: one width throughout
+    add("int_dict_4400_even_codes", pool[even], "dict(bp)")
+    add("int_dict_4400_varying_codes", pool[(_rng(42).integers(0, 4400, N) >> _rng(43).integers(0, 12, N // 32 + 1).repeat(32)[:N])], "dict(bp)")
     # PFOR (SIMDFastPFor<8> + VariableByte) and the legacy PFOR_DELTA
     outliers = _rng(30).integers(0, 1000, N).astype(np.int32)
     outliers[_rng(31).integers(0, N, N // 50)] = _rng(32).integers(0, 2**31 - 1, N // 50).astype(np.int32)
@@ -102,12 +109,20 @@ def cases():
     head_bunch = bunch.copy()
     head_bunch[:9000] = 1.0 / 7.0 * np.arange(1, 9001)
     add("dbl_pseudo_patches_at_start", head_bunch, "pseudodecimal(bp,bp,uncompressed)")
+    mid_bunch = bunch.copy()
+    mid_bunch[30000:33500] = 1.0 / 3.0 * np.arange(1, 3501)
+    add("dbl_pseudo_patches_in_the_middle", mid_bunch, "pseudodecimal(bp,bp,uncompressed)")
+    add("dbl_pseudo_one_exponent", _rng(62).integers(0, 10**7, N).astype(np.float64) * 0.01 + 0.0, "pseudodecimal(bp,bp,uncompressed)")
     wide = (_rng(60).integers(0, 2**31 - 1, N) >> _rng(61).integers(0, 30, N)).astype(np.float64) / 1000.0
     add("dbl_pseudo_wide_digits", wide, "pseudodecimal(bp,bp,uncompressed)")
     add("dbl_pseudo_two_blocks", synth.double_decimal(100000, patch_fraction=0.02), "pseudodecimal(bp,bp,uncompressed)")
     add("dbl_uncompressed", _rng(20).uniform(-1e6, 1e6, 5000), "uncompressed")
     add("dbl_onevalue", np.full(N, 3.25), "onevalue")
     add("dbl_dict_bp", synth.dictionary_values(N, 1020, dtype=np.float64), "dict(bp)")
+    dpool = _rng(44).uniform(-1e9, 1e9, 6000)
+    add("dbl_dict_4000_even_codes", dpool[_rng(45).integers(0, 4000, N)], "dict(bp)")
+    add("dbl_dict_4000_varying_codes", dpool[_rng(46).integers(0, 4000, N) >> _rng(47).integers(0, 12, N // 32 + 1).repeat(32)[:N]], "dict(bp)")
+    add("dbl_dict_6000_global_gather", dpool[_rng(48).integers(0, 6000, N)], "dict(bp)")
     add("dbl_dict8", synth.dictionary_values(65000, 255, dtype=np.float64), "dict8")
     add("dbl_dict16", synth.dictionary_values(65000, 1020, dtype=np.float64), "dict16")
     add("dbl_rle", np.repeat(_rng(21).uniform(-999999, 999999, N // 21 + 1), 21)[:N], "rle(uncompressed,bp)")
