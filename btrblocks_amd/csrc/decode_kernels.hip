@@ -1995,6 +1995,39 @@ __device__ __forceinline__ void vbyte_tail_decode(const Ctx& c, __amdgpu_buffer_
   __syncthreads();
 }
 
+// Wait of a wave that streams packed words into its LDS ring and stores unpacked values in
+// between: everything but the newest `blocks` * 4 store instructions and (if `newer_load`) one
+// load behind them has completed. The wait count is an immediate, so one case per block count;
+// counts beyond the counter's range wait for a little more than needed.
+__device__ __forceinline__ void pfor_wait(u32 blocks, bool newer_load) {
+#define BTR_PFOR_WAIT_CASE(k)                                       \
+  case k:                                                           \
+    if (newer_load)                                                 \
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * k + 1) : "memory"); \
+    else                                                            \
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * k) : "memory");  \
+    break;
+  switch (blocks < 15 ? blocks : 15) {
+    BTR_PFOR_WAIT_CASE(0)
+    BTR_PFOR_WAIT_CASE(1)
+    BTR_PFOR_WAIT_CASE(2)
+    BTR_PFOR_WAIT_CASE(3)
+    BTR_PFOR_WAIT_CASE(4)
+    BTR_PFOR_WAIT_CASE(5)
+    BTR_PFOR_WAIT_CASE(6)
+    BTR_PFOR_WAIT_CASE(7)
+    BTR_PFOR_WAIT_CASE(8)
+    BTR_PFOR_WAIT_CASE(9)
+    BTR_PFOR_WAIT_CASE(10)
+    BTR_PFOR_WAIT_CASE(11)
+    BTR_PFOR_WAIT_CASE(12)
+    BTR_PFOR_WAIT_CASE(13)
+    BTR_PFOR_WAIT_CASE(14)
+    BTR_PFOR_WAIT_CASE(15)
+  }
+#undef BTR_PFOR_WAIT_CASE
+}
+
 __device__ __forceinline__ void pfor_decode(const Ctx& c, const Step& s) {
   const u32 tid = threadIdx.x;
   const u8* base = c.src + uniform(s.a[0]);
@@ -2005,6 +2038,7 @@ __device__ __forceinline__ void pfor_decode(const Ctx& c, const Step& s) {
   const Tab out = resolve_tab(c, uniform(s.a[4]));
   const u32 work = seq_lds(c, uniform(s.a[5]));
   const u32 table_off = work, bytes_lds = work + 4096, tail_off = work + 8192, packed_lds = work + 9472,
+            ebase_off = tail_off,  // 257 words; the tail stage is only used after the pages
             jump_lds = packed_lds, pos_lds = packed_lds + 2 * (4096 + 512);  // dead before the rings fill
   const u32 n = out.count;
   const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(base, W * 4);
@@ -2030,6 +2064,7 @@ __device__ __forceinline__ void pfor_decode(const Ctx& c, const Step& s) {
       auto jt = [&](u32 o) { return jump_lds + 2 * o; };
 #pragma unroll
       for (u32 i = 0; i < 16; i++) {
+        if (i * kBlockThreads >= bytes_size) break;  // offsets behind the container are never visited
         const u32 o = i * kBlockThreads + tid;
         u32 j = kDead + (o & 255);
         if (o + 2 <= bytes_size) {
@@ -2048,14 +2083,16 @@ __device__ __forceinline__ void pfor_decode(const Ctx& c, const Step& s) {
         u32 nj[8];  // J_(t+1) of this thread's sixteen offsets, two per register
 #pragma unroll
         for (u32 i = 0; i < 8; i++)
-          nj[i] = lds16(jt(lds16(jt(2 * i * kBlockThreads + tid)))) |
-                  (lds16(jt(lds16(jt((2 * i + 1) * kBlockThreads + tid)))) << 16);
+          if (2 * i * kBlockThreads < bytes_size)
+            nj[i] = lds16(jt(lds16(jt(2 * i * kBlockThreads + tid)))) |
+                    (lds16(jt(lds16(jt((2 * i + 1) * kBlockThreads + tid)))) << 16);
         __syncthreads();  // every thread has read J_t
 #pragma unroll
-        for (u32 i = 0; i < 8; i++) {
-          *reinterpret_cast<u16*>(lds_raw + jt(2 * i * kBlockThreads + tid)) = (u16)nj[i];
-          *reinterpret_cast<u16*>(lds_raw + jt((2 * i + 1) * kBlockThreads + tid)) = (u16)(nj[i] >> 16);
-        }
+        for (u32 i = 0; i < 8; i++)
+          if (2 * i * kBlockThreads < bytes_size) {
+            *reinterpret_cast<u16*>(lds_raw + jt(2 * i * kBlockThreads + tid)) = (u16)nj[i];
+            *reinterpret_cast<u16*>(lds_raw + jt((2 * i + 1) * kBlockThreads + tid)) = (u16)(nj[i] >> 16);
+          }
         __syncthreads();
       }
       // one thread per block reads its record; the packs' first words are a prefix sum of 8 * b
@@ -2120,6 +2157,13 @@ __device__ __forceinline__ void pfor_decode(const Ctx& c, const Step& s) {
     }
     __syncthreads();
     BTR_STAMP(c, 9);
+    // exceptions in front of each block (for step 4)
+    u32 total_exc;
+    {
+      const u32 cex = tid < blocks ? (lds32(table_off + 16 * tid) >> 8) & 0xFF : 0u;
+      const u32 before = block_exclusive_scan(c, cex, &total_exc);
+      if (tid <= blocks) lds_st32(ebase_off + 4 * tid, before);
+    }
     // 2. index of a block's first exception inside its width class: exceptions of the same width
     //    in the blocks before it
     for (u32 r = tid; r < blocks; r += kBlockThreads) {
@@ -2155,29 +2199,40 @@ __device__ __forceinline__ void pfor_decode(const Ctx& c, const Step& s) {
         issue(0);
         issue(1);
         u32 r = r_begin;
+        const bool to_global = out.loc != LOC_LDS;
+        const __amdgpu_buffer_rsrc_t out_rsrc = make_rsrc(to_global ? out.g : nullptr, to_global ? out.count * 4 : 0);
+        u32 stored = 0;  // blocks stored (four store instructions each) since the last wait
         for (u32 piece = 0; piece < pieces && r < r_end; piece++) {
+          const bool more = piece + 2 < pieces;
           issue(piece + 2);  // its slot held piece - 2
-          // pieces <= piece + 1 have landed (and the stores of the previous iteration are out)
-          if (piece + 2 < pieces)
-            asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-          else
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          // Pieces <= piece + 1 must have landed. Loads and stores complete in issue order on one
+          // counter: behind the load of piece + 1 this wave issued the stores of the previous
+          // iteration and (if any) the load above, and exactly those may stay in flight.
+          pfor_wait(to_global ? stored : 0u, more);
+          stored = 0;
           while (r < r_end) {
             const u32 rel = uniform(lds32(table_off + 16 * r + 12)) - w_lo;
             if (rel >= kPiece * (piece + 1)) break;
             const u32 b = uniform(lds32(table_off + 16 * r)) & 0xFF;
+            const u32 mask = b >= 32 ? ~0u : (1u << b) - 1u;
             u32 v[4];
 #pragma unroll
             for (u32 q = 0; q < 4; q++) {
-              const u32 i = lane + 64 * q;
-              const u32 bit = ((i & 127) >> 2) * b;
-              const u32 w = rel + (i >> 7) * 4 * b + 4 * (bit >> 5) + (i & 3);
+              const u32 bit = ((lane >> 2) + 16 * (q & 1)) * b;
+              const u32 w = rel + (q >> 1) * 4 * b + 4 * (bit >> 5) + (lane & 3);
               const u32 x = __builtin_amdgcn_alignbit(lds32(ring + 4 * ((w + 4) & (kRing - 1))),
                                                       lds32(ring + 4 * (w & (kRing - 1))), bit);
-              v[q] = b >= 32 ? x : (x & ((1u << b) - 1u));
+              v[q] = x & mask;
             }
+            const u32 o = (first + r * btrfmt::PFOR_BLOCK + lane) * 4;
+            if (to_global) {
 #pragma unroll
-            for (u32 q = 0; q < 4; q++) tab_st32(out, first + r * btrfmt::PFOR_BLOCK + lane + 64 * q, v[q]);
+              for (u32 q = 0; q < 4; q++) __builtin_amdgcn_raw_buffer_store_b32(v[q], out_rsrc, o + 256 * q, 0, 0);
+              stored++;
+            } else {
+#pragma unroll
+              for (u32 q = 0; q < 4; q++) lds_st32(out.lds + o + 256 * q, v[q]);
+            }
             r++;
           }
         }
@@ -2185,16 +2240,39 @@ __device__ __forceinline__ void pfor_decode(const Ctx& c, const Step& s) {
     }
     __syncthreads();  // also orders the stores above before the patches below
     BTR_STAMP(c, 11);
-    // 4. exceptions: one thread per block ORs (value >> b) << b back in, by position
-    for (u32 r = tid; r < blocks; r += kBlockThreads) {
-      const u32 e = lds32(table_off + 16 * r), pos_off = lds32(table_off + 16 * r + 4), ex0 = lds32(table_off + 16 * r + 8);
-      const u32 b = e & 0xFF, cex = (e >> 8) & 0xFF, k = e >> 16;
-      if (!cex || b >= 32) continue;
-      const u32 cls_word = k >= 2 ? lds32(d + 4 * (5 + k - 2)) : 0u;
-      const u32 cls_size = k >= 2 ? lds32(d + 4 * (5 + 31 + k - 2)) : 0u;
-      const u32 full = cls_size & ~127u;
-      for (u32 x = 0; x < cex; x++) {
-        const u32 pos = __builtin_amdgcn_raw_buffer_load_b8(rsrc, pos_off + x, 0, 0);  // past the payload: 0
+    // 4. exceptions, one thread each: exception e of the page belongs to the block r with
+    //    ebase[r] <= e < ebase[r + 1]; (value >> b) << b is ORed back in at its position
+    constexpr u32 kPatchUnroll = 4;  // exceptions per thread whose loads are in flight together
+    for (u32 e0 = 0; e0 < total_exc; e0 += kBlockThreads * kPatchUnroll) {
+      u32 at[kPatchUnroll], hi_bits[kPatchUnroll], old[kPatchUnroll];
+      bool live[kPatchUnroll];
+#pragma unroll
+      for (u32 u = 0; u < kPatchUnroll; u++) {
+        const u32 en = e0 + u * kBlockThreads + tid;
+        live[u] = en < total_exc;
+        at[u] = hi_bits[u] = old[u] = 0;
+        if (!live[u]) continue;
+        u32 r = 0, hi = blocks;
+        while (hi - r > 1) {
+          const u32 mid = (r + hi) >> 1;
+          if (lds32(ebase_off + 4 * mid) <= en)
+            r = mid;
+          else
+            hi = mid;
+        }
+        const u32 x = en - lds32(ebase_off + 4 * r);
+        const u32 e = lds32(table_off + 16 * r), pos_off = lds32(table_off + 16 * r + 4), ex0 = lds32(table_off + 16 * r + 8);
+        const u32 b = e & 0xFF, k = e >> 16;
+        if (b >= 32) {
+          live[u] = false;
+          continue;
+        }
+        const u32 cls_word = k >= 2 ? lds32(d + 4 * (5 + k - 2)) : 0u;
+        const u32 cls_size = k >= 2 ? lds32(d + 4 * (5 + 31 + k - 2)) : 0u;
+        const u32 full = cls_size & ~127u;
+        const u32 pos = staged && pos_off + x < bytes_off + bytes_size
+                            ? (u32)lds_raw[bytes_lds + skew + (pos_off - bytes_off) + x]
+                            : __builtin_amdgcn_raw_buffer_load_b8(rsrc, pos_off + x, 0, 0);  // past the payload: 0
         u32 v = 1;
         if (k >= 2) {
           const u32 q = ex0 + x;
@@ -2208,9 +2286,13 @@ __device__ __forceinline__ void pfor_decode(const Ctx& c, const Step& s) {
             v = bp_extract(rsrc, cls_word + (full >> 7) * 4 * k + (qq >> 5) * k, k, qq & 31);
           }
         }
-        const u32 at = first + r * btrfmt::PFOR_BLOCK + pos;
-        tab_st32(out, at, tab_ld32(out, at) | (v << b));
+        at[u] = first + r * btrfmt::PFOR_BLOCK + pos;
+        hi_bits[u] = v << b;
+        old[u] = tab_ld32(out, at[u]);
       }
+#pragma unroll
+      for (u32 u = 0; u < kPatchUnroll; u++)
+        if (live[u]) tab_st32(out, at[u], old[u] | hi_bits[u]);
     }
     __syncthreads();
   }
