@@ -232,7 +232,8 @@ const char* btr_version(void) { return "btrblocks_amd 0.1 (gfx950)"; }
 const char* btr_kernel_name(uint32_t k) {
   static const char* const names[KERNEL_KINDS] = {
       "btr_decode_int_kernel",      "btr_decode_dbl_kernel",      "btr_stream_none_kernel",  "btr_stream_add_kernel",
-      "btr_stream_dict_lds_kernel", "btr_stream_dict_glb_kernel", "btr_stream_pseudo_kernel", "btr_stream_dictd_kernel"};
+      "btr_stream_dict_lds_kernel", "btr_stream_dict_glb_kernel", "btr_stream_pseudo_kernel", "btr_stream_dictd_kernel",
+      "btr_decode_int_pfor_kernel", "btr_decode_dbl_pfor_kernel"};
   return k < KERNEL_KINDS ? names[k] : nullptr;
 }
 
@@ -429,7 +430,8 @@ btr_status btr_gpu_ctx_create(int device, btr_gpu_ctx** out) {
   const void* kernels[] = {(const void*)btr_decode_int_kernel,      (const void*)btr_decode_dbl_kernel,
                            (const void*)btr_stream_none_kernel,     (const void*)btr_stream_add_kernel,
                            (const void*)btr_stream_dict_lds_kernel, (const void*)btr_stream_dict_glb_kernel,
-                           (const void*)btr_stream_pseudo_kernel,   (const void*)btr_stream_dictd_kernel};
+                           (const void*)btr_stream_pseudo_kernel,   (const void*)btr_stream_dictd_kernel,
+                           (const void*)btr_decode_int_pfor_kernel, (const void*)btr_decode_dbl_pfor_kernel};
   for (const void* k : kernels) {
     hipFuncAttributes attr;
     e = hipFuncGetAttributes(&attr, k);
@@ -558,14 +560,15 @@ btr_status btr_gpu_plan_stats(const btr_gpu_plan* plan, btr_plan_stats* out) {
 }
 
 static unsigned threads_of(uint32_t kind) {
-  return kind == KERNEL_STREAM_DICTD ? kDictdThreads : kind >= KERNEL_STREAM_NONE ? kStreamThreads : kBlockThreads;
+  return kind == KERNEL_STREAM_DICTD ? kDictdThreads : kernel_is_generic(kind) ? kBlockThreads : kStreamThreads;
 }
 using DecodeKernel = void (*)(const WorkItem*, const uint32_t*, const uint8_t*, uint32_t*);
 static DecodeKernel kernel_of(uint32_t kind) {
   static const DecodeKernel kernels[KERNEL_KINDS] = {btr_decode_int_kernel,      btr_decode_dbl_kernel,
                                                      btr_stream_none_kernel,     btr_stream_add_kernel,
                                                      btr_stream_dict_lds_kernel, btr_stream_dict_glb_kernel,
-                                                     btr_stream_pseudo_kernel,   btr_stream_dictd_kernel};
+                                                     btr_stream_pseudo_kernel,   btr_stream_dictd_kernel,
+                                                     btr_decode_int_pfor_kernel, btr_decode_dbl_pfor_kernel};
   return kernels[kind];
 }
 

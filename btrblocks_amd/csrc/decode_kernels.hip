@@ -899,7 +899,9 @@ __device__ __forceinline__ void mat_int(const Ctx& c, const IntEval& e, const Ta
 // Root steps of table-driven bases (fill, copy, run expansion, exception patching) write 16 bytes
 // per lane: one bitmap word and one rank lookup serve four rows, and a wave stores 1 KiB per
 // instruction.
-template <u32 BASE>
+// TAB_LDS: the value table is known to sit in LDS (no location test per load, so the four loads
+// of a lane are in flight together).
+template <u32 BASE, bool TAB_LDS = false>
 __device__ __forceinline__ u32x4 eval_int4_base(const IntEval& e, u32 i, __amdgpu_buffer_rsrc_t seq_rsrc) {
   u32x4 v;
   if (BASE == B_ONE) {
@@ -920,10 +922,17 @@ __device__ __forceinline__ u32x4 eval_int4_base(const IntEval& e, u32 i, __amdgp
     r1 = r1 < last ? r1 : last;
     r2 = r2 < last ? r2 : last;
     r3 = r3 < last ? r3 : last;
-    v.x = tab_ld32(e.tab, r0);
-    v.y = tab_ld32(e.tab, r1);
-    v.z = tab_ld32(e.tab, r2);
-    v.w = tab_ld32(e.tab, r3);
+    if (TAB_LDS) {
+      v.x = lds32(e.tab.lds + 4 * r0);
+      v.y = lds32(e.tab.lds + 4 * r1);
+      v.z = lds32(e.tab.lds + 4 * r2);
+      v.w = lds32(e.tab.lds + 4 * r3);
+    } else {
+      v.x = tab_ld32(e.tab, r0);
+      v.y = tab_ld32(e.tab, r1);
+      v.z = tab_ld32(e.tab, r2);
+      v.w = tab_ld32(e.tab, r3);
+    }
   } else {  // B_FREQ: top value unless the row is a bitmap member (templated/Frequency.hpp:118-135)
     const u32 w = i >> 6, p = i & 63;
     const u64 word = lds64(e.rk.bits_off + 8 * w);
@@ -932,13 +941,14 @@ __device__ __forceinline__ u32x4 eval_int4_base(const IntEval& e, u32 i, __amdgp
     if (m) {
       const u32 last = e.tab.count - 1;
       u32 r = lds32(e.rk.rank_off + 4 * w) + __popcll(word & ((1ull << p) - 1));
-      if (m & 1) v.x = tab_ld32(e.tab, r < last ? r : last);
+      auto ld = [&](u32 q) { return TAB_LDS ? lds32(e.tab.lds + 4 * (q < last ? q : last)) : tab_ld32(e.tab, q < last ? q : last); };
+      if (m & 1) v.x = ld(r);
       r += m & 1;
-      if (m & 2) v.y = tab_ld32(e.tab, r < last ? r : last);
+      if (m & 2) v.y = ld(r);
       r += (m >> 1) & 1;
-      if (m & 4) v.z = tab_ld32(e.tab, r < last ? r : last);
+      if (m & 4) v.z = ld(r);
       r += (m >> 2) & 1;
-      if (m & 8) v.w = tab_ld32(e.tab, r < last ? r : last);
+      if (m & 8) v.w = ld(r);
     }
   }
   return v;
@@ -947,7 +957,7 @@ __device__ __forceinline__ u32x4 eval_int4_base(const IntEval& e, u32 i, __amdgp
 constexpr u32 kUnroll4 = 2;
 constexpr int kStoreNt = 2;  // cache policy bit of buffer stores: non-temporal
 
-template <u32 BASE, u32 PS>
+template <u32 BASE, u32 PS, bool TAB_LDS = false>
 __device__ __forceinline__ void mat_int4(const Ctx& c, const IntEval& e, u32* __restrict__ dst, u32 count) {
   const u32 tid = threadIdx.x;
   const u32 quads = count & ~3u;
@@ -955,12 +965,16 @@ __device__ __forceinline__ void mat_int4(const Ctx& c, const IntEval& e, u32* __
       BASE == B_SEQ ? (e.tab.loc == LOC_LDS ? make_rsrc(nullptr, 0) : make_rsrc(e.tab.g, e.tab.count * 4))
                     : make_rsrc(nullptr, 0);
   u32 bad = 0;
-  for (u32 base = 0; base < quads; base += kBlockThreads * 4 * kUnroll4) {
+  constexpr u32 kRowsPerIter = kBlockThreads * 4 * kUnroll4;
+  // whole iterations need no row clamps and no store predicates
+  const u32 whole = quads / kRowsPerIter * kRowsPerIter;
+  auto iteration = [&](u32 base, auto tag) {
+    constexpr bool PARTIAL = decltype(tag)::value;
     u32x4 v[kUnroll4];
 #pragma unroll
     for (u32 u = 0; u < kUnroll4; u++) {
       const u32 i = base + (u * kBlockThreads + tid) * 4;
-      v[u] = eval_int4_base<BASE>(e, i < quads ? i : quads - 4, seq_rsrc);
+      v[u] = eval_int4_base<BASE, TAB_LDS>(e, PARTIAL ? (i < quads ? i : quads - 4) : i, seq_rsrc);
     }
 #pragma unroll
     for (u32 u = 0; u < kUnroll4; u++) {
@@ -974,9 +988,11 @@ __device__ __forceinline__ void mat_int4(const Ctx& c, const IntEval& e, u32* __
       const u32 i = base + (u * kBlockThreads + tid) * 4;
       // non-temporal: the decoded column is written once and not read back by this kernel; keeping
       // it out of the caches also keeps its write-back out of the next launch's time
-      if (i < quads) __builtin_nontemporal_store(v[u], reinterpret_cast<u32x4*>(dst + i));
+      if (!PARTIAL || i < quads) __builtin_nontemporal_store(v[u], reinterpret_cast<u32x4*>(dst + i));
     }
-  }
+  };
+  for (u32 base = 0; base < whole; base += kRowsPerIter) iteration(base, std::false_type{});
+  if (whole < quads) iteration(whole, std::true_type{});
   if (tid < count - quads) dst[quads + tid] = eval_int<BASE, false, PS>(e, quads + tid, bad);
   report(c, bad);
 }
@@ -992,6 +1008,14 @@ __device__ __forceinline__ bool wide_rows(const IntEval& e, const Tab& out, u32 
 template <u32 BASE>
 __device__ __forceinline__ void mat_int4_ps(const Ctx& c, const IntEval& e, const Tab& out, u32 count) {
   u32* dst = reinterpret_cast<u32*>(const_cast<u8*>(out.g));
+  if ((BASE == B_RLE || BASE == B_FREQ) && e.tab.loc == LOC_LDS && e.tab.count > 0) {
+    switch (post_signature(e)) {
+      case PS_NONE: mat_int4<BASE, PS_NONE, true>(c, e, dst, count); return;
+      case PS_ADD: mat_int4<BASE, PS_ADD, true>(c, e, dst, count); return;
+      case PS_DICT_LDS: mat_int4<BASE, PS_DICT_LDS, true>(c, e, dst, count); return;
+      default: break;
+    }
+  }
   switch (post_signature(e)) {
     case PS_NONE: mat_int4<BASE, PS_NONE>(c, e, dst, count); break;
     case PS_ADD: mat_int4<BASE, PS_ADD>(c, e, dst, count); break;
@@ -1710,7 +1734,7 @@ __device__ __forceinline__ void mat_dbl(const Ctx& c, const DblEval& e, const Ta
 // of mat_int4.
 typedef u64 u64x2 __attribute__((ext_vector_type(2)));
 
-template <u32 BASE>
+template <u32 BASE, bool TAB_LDS = false>
 __device__ __forceinline__ u64x2 eval_dbl2_base(const DblEval& e, u32 i, __amdgpu_buffer_rsrc_t seq_rsrc) {
   u64x2 v;
   if (BASE == B_ONE) {
@@ -1728,8 +1752,8 @@ __device__ __forceinline__ u64x2 eval_dbl2_base(const DblEval& e, u32 i, __amdgp
     u32 r1 = r0 + ((u32)(word >> (p + 1)) & 1);
     r0 = r0 < last ? r0 : last;
     r1 = r1 < last ? r1 : last;
-    v.x = tab_ld64(e.tab, r0);
-    v.y = tab_ld64(e.tab, r1);
+    v.x = TAB_LDS ? lds64(e.tab.lds + 8 * r0) : tab_ld64(e.tab, r0);
+    v.y = TAB_LDS ? lds64(e.tab.lds + 8 * r1) : tab_ld64(e.tab, r1);
   } else {  // B_FREQ
     const u32 w = i >> 6, p = i & 63;
     const u64 word = lds64(e.rk.bits_off + 8 * w);
@@ -1746,25 +1770,30 @@ __device__ __forceinline__ u64x2 eval_dbl2_base(const DblEval& e, u32 i, __amdgp
   return v;
 }
 
-template <u32 BASE>
+template <u32 BASE, bool TAB_LDS = false>
 __device__ __forceinline__ void mat_dbl2(const Ctx& c, const DblEval& e, u64* __restrict__ dst, u32 count) {
   const u32 tid = threadIdx.x;
   const u32 pairs = count & ~1u;
   const __amdgpu_buffer_rsrc_t seq_rsrc =
       BASE == B_SEQ && e.tab.loc != LOC_LDS ? make_rsrc(e.tab.g, e.tab.count * 8) : make_rsrc(nullptr, 0);
-  for (u32 base = 0; base < pairs; base += kBlockThreads * 2 * kUnroll4) {
+  constexpr u32 kRowsPerIter = kBlockThreads * 2 * kUnroll4;
+  const u32 whole = pairs / kRowsPerIter * kRowsPerIter;  // whole iterations: no clamps, no store predicates
+  auto iteration = [&](u32 base, auto tag) {
+    constexpr bool PARTIAL = decltype(tag)::value;
     u64x2 v[kUnroll4];
 #pragma unroll
     for (u32 u = 0; u < kUnroll4; u++) {
       const u32 i = base + (u * kBlockThreads + tid) * 2;
-      v[u] = eval_dbl2_base<BASE>(e, i < pairs ? i : pairs - 2, seq_rsrc);
+      v[u] = eval_dbl2_base<BASE, TAB_LDS>(e, PARTIAL ? (i < pairs ? i : pairs - 2) : i, seq_rsrc);
     }
 #pragma unroll
     for (u32 u = 0; u < kUnroll4; u++) {
       const u32 i = base + (u * kBlockThreads + tid) * 2;
-      if (i < pairs) __builtin_nontemporal_store(v[u], reinterpret_cast<u64x2*>(dst + i));
+      if (!PARTIAL || i < pairs) __builtin_nontemporal_store(v[u], reinterpret_cast<u64x2*>(dst + i));
     }
-  }
+  };
+  for (u32 base = 0; base < whole; base += kRowsPerIter) iteration(base, std::false_type{});
+  if (whole < pairs) iteration(whole, std::true_type{});
   u32 bad = 0;
   if (tid < count - pairs) dst[pairs + tid] = eval_dbl<BASE, GEN, GEN, PS_GEN>(e, pairs + tid, bad);
 }
@@ -1826,7 +1855,12 @@ __device__ __forceinline__ void materialize(const Ctx& c, u32 pipe_id, u32 seq_i
       switch (e.base) {
         case B_SEQ: mat_dbl2<B_SEQ>(c, e, dst, count); break;
         case B_ONE: mat_dbl2<B_ONE>(c, e, dst, count); break;
-        case B_RLE: mat_dbl2<B_RLE>(c, e, dst, count); break;
+        case B_RLE:
+          if (e.tab.loc == LOC_LDS)
+            mat_dbl2<B_RLE, true>(c, e, dst, count);
+          else
+            mat_dbl2<B_RLE>(c, e, dst, count);
+          break;
         default: mat_dbl2<B_FREQ>(c, e, dst, count); break;
       }
       return;
@@ -2544,7 +2578,7 @@ __device__ __forceinline__ void stream_pseudo_block(const WorkItem* __restrict__
   stamp(it, 5);
 }
 
-template <bool DOUBLE_KERNEL>
+template <bool DOUBLE_KERNEL, bool WITH_PFOR>
 __device__ __forceinline__ void decode_block(const WorkItem* __restrict__ items, const u32* __restrict__ order,
                                     const u8* __restrict__ programs, u32* __restrict__ status) {
   const u32 item = order[blockIdx.x];
@@ -2575,7 +2609,9 @@ __device__ __forceinline__ void decode_block(const WorkItem* __restrict__ items,
       case S_BITMAP_EQ: bitmap_eq(c, st); break;
       case S_BITMAP_RANK: bitmap_rank(c, st); break;
       case S_NULLMAP: write_nullmap(c, st); break;
-      case S_PFOR_DECODE: pfor_decode(c, st); break;
+      case S_PFOR_DECODE:
+        if (WITH_PFOR) pfor_decode(c, st);
+        break;
       default: break;
     }
     __syncthreads();
@@ -2590,13 +2626,13 @@ __device__ __forceinline__ void decode_block(const WorkItem* __restrict__ items,
 extern "C" __global__ void __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(6, 8)))
 btr_decode_int_kernel(const WorkItem* __restrict__ items, const u32* __restrict__ order,
                       const u8* __restrict__ programs, u32* __restrict__ status) {
-  decode_block<false>(items, order, programs, status);
+  decode_block<false, false>(items, order, programs, status);
 }
 
 extern "C" __global__ void __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(5, 8)))
 btr_decode_dbl_kernel(const WorkItem* __restrict__ items, const u32* __restrict__ order,
                       const u8* __restrict__ programs, u32* __restrict__ status) {
-  decode_block<true>(items, order, programs, status);
+  decode_block<true, false>(items, order, programs, status);
 }
 
 // Streamed bit-packed integer roots, one kernel per post-op signature (plan.h: KERNEL_STREAM_*).
@@ -2631,4 +2667,17 @@ extern "C" __global__ void __launch_bounds__(kDictdThreads)
 btr_stream_dictd_kernel(const WorkItem* __restrict__ items, const u32* __restrict__ order,
                         const u8* __restrict__ programs, u32* __restrict__ status) {
   stream_dictd_block(items, order, programs, status);
+}
+
+// The generic kernels with the PFOR step (plan.h: KERNEL_PFOR_INT / KERNEL_PFOR_DBL).
+extern "C" __global__ void __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(6, 8)))
+btr_decode_int_pfor_kernel(const WorkItem* __restrict__ items, const u32* __restrict__ order,
+                           const u8* __restrict__ programs, u32* __restrict__ status) {
+  decode_block<false, true>(items, order, programs, status);
+}
+
+extern "C" __global__ void __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(5, 8)))
+btr_decode_dbl_pfor_kernel(const WorkItem* __restrict__ items, const u32* __restrict__ order,
+                           const u8* __restrict__ programs, u32* __restrict__ status) {
+  decode_block<true, true>(items, order, programs, status);
 }

@@ -155,8 +155,11 @@ enum : uint32_t {
   KERNEL_STREAM_DICT_GLB = 5,  // DICT(BP), dictionary read from the compressed bytes
   KERNEL_STREAM_PSEUDO = 6,    // PSEUDODECIMAL(BP,BP,raw patches) doubles: digits through the ring
   KERNEL_STREAM_DICTD = 7,     // DICT(BP) doubles, dictionary staged in LDS or read from the compressed bytes
-  KERNEL_KINDS = 8,
+  KERNEL_PFOR_INT = 8,         // the generic kernels again, with the S_PFOR_DECODE step compiled in (the
+  KERNEL_PFOR_DBL = 9,         // plain ones leave it out: it costs every other program registers)
+  KERNEL_KINDS = 10,
 };
+constexpr bool kernel_is_generic(uint32_t k) { return k <= KERNEL_GENERIC_DBL || k >= KERNEL_PFOR_INT; }
 
 constexpr uint32_t kBlockThreads = 256;
 constexpr uint32_t kStreamRingBytes = 16 * 1024;  // LDS ring of the streamed root step (4 batches of 1024 words)

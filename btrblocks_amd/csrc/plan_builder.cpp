@@ -627,6 +627,9 @@ void build_program(const ColumnSource& src, BuiltProgram& out) {
       if (!direct) bld.add_step(S_MATERIALIZE, root, dst);
     }
   }
+  if (kernel_is_generic(kernel))
+    for (const Step& st : bld.steps)
+      if (st.kind == S_PFOR_DECODE) kernel = src.column_type == COL_DOUBLE ? KERNEL_PFOR_DBL : KERNEL_PFOR_INT;
   // LDS scratch for the header-chain walkers: index step s runs on wave s % 4, so four slots
   // cover every program; the streamed root's walker starts after the index steps and reuses slot 0.
   uint32_t walk_scratch[4] = {NONE, NONE, NONE, NONE};
@@ -637,7 +640,7 @@ void build_program(const ColumnSource& src, BuiltProgram& out) {
     };
     for (size_t k = 0; k < bld.bp_steps.size(); k++)
       if (bld.pipes[bld.bp_steps[k].a[0]].a[5] > kWalkScratchMinGroups) bld.bp_steps[k].a[1] = scratch_slot(k % 4);
-    if (kernel != KERNEL_GENERIC_INT && kernel != KERNEL_GENERIC_DBL) bld.steps.back().a[3] = scratch_slot(0);
+    if (!kernel_is_generic(kernel)) bld.steps.back().a[3] = scratch_slot(0);
   }
   if (src.want_nullmap) {
     if (src.nullmap_type == NM_REGULAR || src.nullmap_type == NM_FLIPPED) {
@@ -665,7 +668,7 @@ void build_program(const ColumnSource& src, BuiltProgram& out) {
         s.off = (uint32_t)lds;
         lds += align_up(s.count * s.esize, 16);
       }
-    if (table_base + lds > kLdsCapBytes && kernel <= KERNEL_GENERIC_DBL) {
+    if (table_base + lds > kLdsCapBytes && kernel_is_generic(kernel)) {
       // very large blocks: give up the walkers' jump tables (they only speed the index steps up)
       for (uint32_t k = 0; k < 4; k++)
         if (walk_scratch[k] != NONE) {
@@ -684,7 +687,7 @@ void build_program(const ColumnSource& src, BuiltProgram& out) {
       // one shared region for the transient tables, sized for the largest
       uint64_t shared = 0;
       for (uint32_t id : bld.transient) shared = std::max<uint64_t>(shared, align_up(bld.seqs[id].count * bld.seqs[id].esize, 16));
-      const uint32_t cap = kernel <= KERNEL_GENERIC_DBL ? kLdsSoftCapGeneric : kLdsSoftCapStream;
+      const uint32_t cap = kernel_is_generic(kernel) ? kLdsSoftCapGeneric : kLdsSoftCapStream;
       if (shared && table_base + lds + shared <= cap) {
         for (uint32_t id : bld.transient) {
           bld.seqs[id].off = (uint32_t)lds;
@@ -696,7 +699,7 @@ void build_program(const ColumnSource& src, BuiltProgram& out) {
     for (auto& s : bld.seqs)
       if (s.loc == LOC_LDS && !s.must_lds) {
         const uint64_t bytes = align_up(s.count * s.esize, 16);
-        if (table_base + lds + bytes <= (kernel <= KERNEL_GENERIC_DBL ? kLdsSoftCapGeneric : kLdsSoftCapStream)) {
+        if (table_base + lds + bytes <= (kernel_is_generic(kernel) ? kLdsSoftCapGeneric : kLdsSoftCapStream)) {
           s.off = (uint32_t)lds;
           lds += bytes;
         } else {
@@ -708,7 +711,7 @@ void build_program(const ColumnSource& src, BuiltProgram& out) {
   };
   const std::vector<Seq> unplaced = bld.seqs;
   place_tables();
-  if (kernel >= KERNEL_STREAM_NONE && kernel != KERNEL_STREAM_PSEUDO && bld.steps.back().a[3] != NONE) {
+  if (!kernel_is_generic(kernel) && kernel != KERNEL_STREAM_PSEUDO && bld.steps.back().a[3] != NONE) {
     // A stream kernel runs at most four 512-thread workgroups per CU, fewer when LDS runs out. The
     // walker's jump table only speeds up streams whose group lengths vary: when all groups of this
     // stream are equally long, give it up if that lets one more workgroup share the CU.
