@@ -1557,24 +1557,53 @@ __device__ __forceinline__ void stream_pseudo(const Ctx& c, const Pipe& root, co
         // exponent groups [r_lo / 128, r_hi / 128), two per iteration, every lane four rows. A second
         // group behind the end repeats the first one with dropped stores.
         const u32 g_end = r_hi >> 7;
+        // The wave-uniform facts of an iteration's two groups are worked out in vector form (lane j
+        // for group j) and handed over by lane reads: far fewer scalar instructions than one
+        // dependent chain per group. The 128 rows of an exponent group use at most 128 consecutive
+        // digits, i.e. two digit groups, the first of them known from the rank in front of the
+        // group. Straight path: both digit groups packed with one width below 32 (the lane's digit
+        // then sits at a bit offset linear in its index) and all exponent widths <= 5 (a value is
+        // a table index as it is).
         for (u32 G0 = (r_lo >> 7) + uw; G0 < g_end; G0 += 2 * kUnpackWaves) {
-          // Wave-uniform facts. The 128 rows of an exponent group use at most 128 consecutive
-          // digits, i.e. two digit groups, the first of them known from the rank in front of the
-          // group. Straight path: both digit groups packed with one width below 32 (the lane's
-          // digit then sits at a bit offset linear in its index) and all exponent widths <= 5
-          // (a value is a table index as it is).
+          const bool have2 = G0 + kUnpackWaves < g_end;  // else the first group again, with dropped stores
+          u32 f_efirst, f_ehdr, f_digit, f_before, f_width;
+          {
+            const u32 Gs = (lane & 1) && have2 ? G0 + kUnpackWaves : G0;
+            const u64 ee = lds64(be.index_off + 8 * Gs);
+            const u32 b0 = lds32(rk.rank_off + 8 * Gs), b1 = lds32(rk.rank_off + 8 * Gs + 4);
+            u32 gd = (Gs * btrfmt::FBP_GROUP - b0) >> 7;
+            gd = gd < groups_d ? gd : groups_d - 1;
+            const u64 q0 = lds64(bd.index_off + 8 * gd), q1 = lds64(bd.index_off + 8 * gd + 8);
+            const u32 eh = (u32)(ee >> 32), h0 = (u32)(q0 >> 32), h1 = (u32)(q1 >> 32), bw = h0 & 0xFF;
+            const bool st = (eh & 0xF8F8F8F8u) == 0 && ((eh + 0x02020202u) & 0xF8F8F8F8u) == 0 &&
+                            h0 == bw * 0x01010101u && (h1 == h0 || gd + 1 >= groups_d) && bw < 32;
+            f_efirst = (u32)ee;
+            f_ehdr = eh;
+            f_digit = (u32)q0 | ((Gs - gd) << 20);  // first payload word of the digit group (< 2^20) | groups ahead (< 2^10)
+            f_before = b0 | ((b1 - b0) << 24);      // exceptions before the group (<= 2^16) | in its first half (<= 64)
+            f_width = bw | (st ? 256u : 0u);
+          }
           u32 Gc[2], e_first[2], e_hdr[2], before[2][2], d_word[2], d_bw[2], d_rel[2], out_base[2];
+          bool straight = true;
           // Loads first, in the order their addresses become known, so that the latencies overlap:
           // exponent words (global), exception bits -> patch candidates (global), then the digits.
           u32x2 ew[2][2], pw[2][2];
           u32 eb[2][2], ebit[2][2], in[2][2];
 #pragma unroll
           for (u32 j = 0; j < 2; j++) {
-            const u32 G = G0 + j * kUnpackWaves;
-            Gc[j] = G < g_end ? G : G0;
-            out_base[j] = G < g_end ? G * (btrfmt::FBP_GROUP * 8) : 0x80000000u;  // out of range: dropped
-            const u64 ee = lds64(be.index_off + 8 * Gc[j]);
-            e_first[j] = uniform((u32)ee), e_hdr[j] = uniform((u32)(ee >> 32));
+            const bool have = j == 0 || have2;
+            Gc[j] = have ? G0 + j * kUnpackWaves : G0;
+            out_base[j] = have ? Gc[j] * (btrfmt::FBP_GROUP * 8) : 0x80000000u;  // out of range: dropped
+            e_first[j] = __builtin_amdgcn_readlane(f_efirst, j);
+            e_hdr[j] = __builtin_amdgcn_readlane(f_ehdr, j);
+            const u32 fd = __builtin_amdgcn_readlane(f_digit, j), fb = __builtin_amdgcn_readlane(f_before, j),
+                      fw = __builtin_amdgcn_readlane(f_width, j);
+            d_word[j] = fd & 0xFFFFF;
+            d_rel[j] = (fd >> 20) * btrfmt::FBP_GROUP;
+            before[j][0] = fb & 0xFFFFFF;
+            before[j][1] = before[j][0] + (fb >> 24);
+            d_bw[j] = fw & 0xFF;
+            straight = straight && (fw >> 8) != 0;
 #pragma unroll
             for (u32 h = 0; h < 2; h++) {
               eb[j][h] = __builtin_amdgcn_ubfe(e_hdr[j], h ? u.sh_hi : u.sh_lo, 8);
@@ -1585,8 +1614,6 @@ __device__ __forceinline__ void stream_pseudo(const Ctx& c, const Pipe& root, co
           }
 #pragma unroll
           for (u32 j = 0; j < 2; j++) {
-            before[j][0] = uniform(lds32(rk.rank_off + 8 * Gc[j]));
-            before[j][1] = uniform(lds32(rk.rank_off + 8 * Gc[j] + 4));
             const u64 m0 = lds64(rk.bits_off + 16 * Gc[j]), m1 = lds64(rk.bits_off + 16 * Gc[j] + 8);
             // exceptions in front of this lane's rows inside their 64-row halves
             in[j][0] = __builtin_amdgcn_mbcnt_hi((u32)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((u32)m0, 0u));
@@ -1594,19 +1621,6 @@ __device__ __forceinline__ void stream_pseudo(const Ctx& c, const Pipe& root, co
 #pragma unroll
             for (u32 h = 0; h < 2; h++)
               pw[j][h] = __builtin_amdgcn_raw_buffer_load_b64(rsrc_p, (before[j][h] + in[j][h]) * 8, 0, 0);
-          }
-          bool straight = true;
-#pragma unroll
-          for (u32 j = 0; j < 2; j++) {
-            u32 gd = (Gc[j] * btrfmt::FBP_GROUP - before[j][0]) >> 7;
-            gd = gd < groups_d ? gd : groups_d - 1;
-            const u64 q0 = lds64(bd.index_off + 8 * gd), q1 = lds64(bd.index_off + 8 * gd + 8);
-            const u32 h0 = uniform((u32)(q0 >> 32)), h1 = uniform((u32)(q1 >> 32));
-            d_word[j] = uniform((u32)q0);
-            d_bw[j] = h0 & 0xFF;
-            d_rel[j] = (Gc[j] - gd) * btrfmt::FBP_GROUP;
-            straight = straight && (e_hdr[j] & 0xF8F8F8F8u) == 0 && ((e_hdr[j] + 0x02020202u) & 0xF8F8F8F8u) == 0 &&
-                       h0 == d_bw[j] * 0x01010101u && (h1 == h0 || gd + 1 >= groups_d) && d_bw[j] < 32;
           }
           auto rows = [&](auto tag) {
             constexpr bool STRAIGHT = decltype(tag)::value;
