@@ -1236,15 +1236,34 @@ template <u32 PS>
 __device__ __forceinline__ void ring_eval_groups(const StreamPost& sp, const UnpackLane& u,
                                                  __amdgpu_buffer_rsrc_t dst_rsrc, u32 index_off, u32 g_lo, u32 g_hi,
                                                  u32 uw, u32& code_max) {
+  const u32 lane = threadIdx.x & 63;
   for (u32 g = g_lo + uw; g < g_hi; g += 2 * kUnpackWaves) {
     const u32 g2 = g + kUnpackWaves;
     const bool two = g2 < g_hi;
     const u64 e1 = lds64(index_off + 8 * g), e2 = lds64(index_off + 8 * (two ? g2 : g));
+    // the index entries are wave-uniform: when the four miniblocks of a group share one width b < 32
+    // its 128 values are one bit string, value v at bit v * b, and the lane's two values (v = lane
+    // and lane + 64) sit 2 * b words apart at the same bit offset
+    const u32 f1 = uniform((u32)e1), h1 = uniform((u32)(e1 >> 32)), f2 = uniform((u32)e2), h2 = uniform((u32)(e2 >> 32));
+    const u32 b1 = h1 & 0xFF, b2 = h2 & 0xFF;
     u32 v[4];
-    v[0] = ring_extract((u32)e1, (u32)(e1 >> 32), u.sh_lo, u.pm_lo, u.k);
-    v[1] = ring_extract((u32)e1, (u32)(e1 >> 32), u.sh_hi, u.pm_hi, u.k);
-    v[2] = ring_extract((u32)e2, (u32)(e2 >> 32), u.sh_lo, u.pm_lo, u.k);
-    v[3] = ring_extract((u32)e2, (u32)(e2 >> 32), u.sh_hi, u.pm_hi, u.k);
+    if (h1 == b1 * 0x01010101u && h2 == b2 * 0x01010101u && b1 < 32 && b2 < 32) {
+#pragma unroll
+      for (u32 j = 0; j < 2; j++) {
+        const u32 b = j ? b2 : b1, f = j ? f2 : f1;
+        u32 bit;
+        asm("v_mul_u32_u24_e32 %0, %1, %2" : "=v"(bit) : "s"(b), "v"(lane));
+        const u32 a = (f + (bit >> 5)) << 2;
+        const u32x2 lo = ring_pair(a & (kStreamRingBytes - 1)), hi = ring_pair((a + 8 * b) & (kStreamRingBytes - 1));
+        v[2 * j] = __builtin_amdgcn_ubfe(__builtin_amdgcn_alignbit(lo.y, lo.x, bit), 0u, b);
+        v[2 * j + 1] = __builtin_amdgcn_ubfe(__builtin_amdgcn_alignbit(hi.y, hi.x, bit), 0u, b);
+      }
+    } else {
+      v[0] = ring_extract(f1, h1, u.sh_lo, u.pm_lo, u.k);
+      v[1] = ring_extract(f1, h1, u.sh_hi, u.pm_hi, u.k);
+      v[2] = ring_extract(f2, h2, u.sh_lo, u.pm_lo, u.k);
+      v[3] = ring_extract(f2, h2, u.sh_hi, u.pm_hi, u.k);
+    }
 #pragma unroll
     for (u32 j = 0; j < 4; j++) v[j] = stream_post<PS>(sp, v[j], code_max);
     const u32 o1 = g * (btrfmt::FBP_GROUP * 4) + u.row4;
