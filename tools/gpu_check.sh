@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: gpu_check.sh <tag> [bench args]   -- parity tests, then bench (plain + root-skipped)
+# usage (from the repository root): tools/gpu_check.sh <tag> [bench args]   -- parity tests, then bench (plain + root-skipped)
 tag=$1; shift
 mkdir -p gpurun_out
 timeout -k 10 300 python -u -m pytest tests/test_gpu_parity.py -m gpu -x -q --timeout 120 --timeout-method thread > gpurun_out/parity_$tag.log 2>&1

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: gpu_dbg.sh "<flag list>" "<columns>"
+# usage (from the repository root): tools/gpu_dbg.sh "<flag list>" "<columns>"
 for f in $1; do
 BTR_DEBUG_FLAGS=$f timeout -k 10 200 python -u bench.py --steps 10 --warmup 2 --no-cpu-baseline --columns $2 > gpurun_out/dbg_$f.log 2>&1
 python - <<PY

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: gpu_sq.sh <columns>  -- SQ instruction counters of the decode kernels of one bench run
+# usage (from the repository root): tools/gpu_sq.sh <columns>  -- SQ instruction counters of the decode kernels of one bench run
 export TMPDIR=/tmp
 out=gpurun_out
 rm -rf $out/sq
