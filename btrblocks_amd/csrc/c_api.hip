@@ -453,24 +453,36 @@ btr_status btr_gpu_plan_create(btr_gpu_ctx* ctx, const btr_chunk_desc* chunks, s
   std::vector<WorkItem> items(n);
   std::vector<BuiltProgram> progs(n);
   std::vector<uint8_t> is_double(n, 0);
-  btr_plan_stats stats{};
-  for (size_t i = 0; i < n; i++) {
+  std::vector<btr_chunk_info> infos(n);
+  // Header walk and validation of one chunk; chunks are independent, so large plans are compiled on
+  // several host threads (the first failing chunk is the one reported).
+  auto compile = [&](size_t i, std::string& err) -> btr_status {
     const btr_chunk_desc& d = chunks[i];
-    if (!d.host_src || !d.dev_src || !d.dev_dst)
-      return fail(BTR_ERR_INVALID_ARGUMENT, "chunk " + std::to_string(i) + ": null pointer");
-    btr_chunk_info info;
+    if (!d.host_src || !d.dev_src || !d.dev_dst) {
+      err = "null pointer";
+      return BTR_ERR_INVALID_ARGUMENT;
+    }
+    btr_chunk_info& info = infos[i];
     btr_status st = parse_chunk((const uint8_t*)d.host_src, d.src_bytes, &info);
-    if (st != BTR_OK) return fail(st, "chunk " + std::to_string(i) + ": " + g_error);
-    if (d.dst_bytes < info.decoded_bytes)
-      return fail(BTR_ERR_BUFFER_TOO_SMALL, "chunk " + std::to_string(i) + ": destination too small");
-    if ((uint64_t)(uintptr_t)d.dev_dst % 8 != 0)
-      return fail(BTR_ERR_MISALIGNED, "chunk " + std::to_string(i) + ": destination must be 8-byte aligned");
+    if (st != BTR_OK) {
+      err = g_error;
+      return st;
+    }
+    if (d.dst_bytes < info.decoded_bytes) {
+      err = "destination too small";
+      return BTR_ERR_BUFFER_TOO_SMALL;
+    }
+    if ((uint64_t)(uintptr_t)d.dev_dst % 8 != 0) {
+      err = "destination must be 8-byte aligned";
+      return BTR_ERR_MISALIGNED;
+    }
     try {
       build_program(chunk_source((const uint8_t*)d.host_src, d.src_bytes, (uint64_t)(uintptr_t)d.dev_src, info,
                                  d.dev_nullmap_dst != nullptr),
                     progs[i]);
     } catch (const PlanError& e) {
-      return fail((btr_status)e.status, "chunk " + std::to_string(i) + ": " + e.what());
+      err = e.what();
+      return (btr_status)e.status;
     }
     WorkItem& it = items[i];
     it.src = (uint64_t)(uintptr_t)d.dev_src;
@@ -479,11 +491,40 @@ btr_status btr_gpu_plan_create(btr_gpu_ctx* ctx, const btr_chunk_desc* chunks, s
     it.tuple_count = info.tuple_count;
     it.src_bytes = (uint32_t)d.src_bytes;
     is_double[i] = info.column_type == COL_DOUBLE;
-    stats.tuples += info.tuple_count;
-    stats.decoded_bytes += info.decoded_bytes;
-    stats.stored_bytes += d.src_bytes;
+    return BTR_OK;
+  };
+  const size_t hw = std::max(1u, std::thread::hardware_concurrency());
+  const size_t workers = n < 256 ? 1 : std::min<size_t>({hw, 16, n / 128});
+  std::vector<size_t> bad_at(workers, n);
+  std::vector<btr_status> bad_status(workers, BTR_OK);
+  std::vector<std::string> bad_text(workers);
+  auto run = [&](size_t w) {
+    const size_t lo = n * w / workers, hi = n * (w + 1) / workers;
+    for (size_t i = lo; i < hi; i++) {
+      const btr_status st = compile(i, bad_text[w]);
+      if (st != BTR_OK) {
+        bad_at[w] = i;
+        bad_status[w] = st;
+        return;
+      }
+    }
+  };
+  if (workers == 1) {
+    run(0);
+  } else {
+    std::vector<std::thread> pool;
+    for (size_t w = 0; w < workers; w++) pool.emplace_back(run, w);
+    for (auto& t : pool) t.join();
+  }
+  for (size_t w = 0; w < workers; w++)  // ranges are in chunk order: the first failure is the lowest index
+    if (bad_status[w] != BTR_OK) return fail(bad_status[w], "chunk " + std::to_string(bad_at[w]) + ": " + bad_text[w]);
+  btr_plan_stats stats{};
+  for (size_t i = 0; i < n; i++) {
+    stats.tuples += infos[i].tuple_count;
+    stats.decoded_bytes += infos[i].decoded_bytes;
+    stats.stored_bytes += chunks[i].src_bytes;
     stats.needed_bytes += CHUNK_DATA;
-    if (d.dev_nullmap_dst) stats.nullmap_bytes += info.tuple_count;
+    if (chunks[i].dev_nullmap_dst) stats.nullmap_bytes += infos[i].tuple_count;
   }
   return finish_plan(ctx, items, progs, is_double, stats, out);
 }
