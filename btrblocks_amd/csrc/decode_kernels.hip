@@ -965,26 +965,28 @@ __device__ __forceinline__ void mat_int4(const Ctx& c, const IntEval& e, u32* __
       BASE == B_SEQ ? (e.tab.loc == LOC_LDS ? make_rsrc(nullptr, 0) : make_rsrc(e.tab.g, e.tab.count * 4))
                     : make_rsrc(nullptr, 0);
   u32 bad = 0;
-  constexpr u32 kRowsPerIter = kBlockThreads * 4 * kUnroll4;
+  // a plain copy has nothing but its loads to wait for: more of them in flight
+  constexpr u32 kUnrollHere = BASE == B_SEQ ? 2 * kUnroll4 : kUnroll4;
+  constexpr u32 kRowsPerIter = kBlockThreads * 4 * kUnrollHere;
   // whole iterations need no row clamps and no store predicates
   const u32 whole = quads / kRowsPerIter * kRowsPerIter;
   auto iteration = [&](u32 base, auto tag) {
     constexpr bool PARTIAL = decltype(tag)::value;
-    u32x4 v[kUnroll4];
+    u32x4 v[kUnrollHere];
 #pragma unroll
-    for (u32 u = 0; u < kUnroll4; u++) {
+    for (u32 u = 0; u < kUnrollHere; u++) {
       const u32 i = base + (u * kBlockThreads + tid) * 4;
       v[u] = eval_int4_base<BASE, TAB_LDS>(e, PARTIAL ? (i < quads ? i : quads - 4) : i, seq_rsrc);
     }
 #pragma unroll
-    for (u32 u = 0; u < kUnroll4; u++) {
+    for (u32 u = 0; u < kUnrollHere; u++) {
       v[u].x = apply_posts<PS>(e, v[u].x, bad);
       v[u].y = apply_posts<PS>(e, v[u].y, bad);
       v[u].z = apply_posts<PS>(e, v[u].z, bad);
       v[u].w = apply_posts<PS>(e, v[u].w, bad);
     }
 #pragma unroll
-    for (u32 u = 0; u < kUnroll4; u++) {
+    for (u32 u = 0; u < kUnrollHere; u++) {
       const u32 i = base + (u * kBlockThreads + tid) * 4;
       // non-temporal: the decoded column is written once and not read back by this kernel; keeping
       // it out of the caches also keeps its write-back out of the next launch's time
@@ -1809,18 +1811,19 @@ __device__ __forceinline__ void mat_dbl2(const Ctx& c, const DblEval& e, u64* __
   const u32 pairs = count & ~1u;
   const __amdgpu_buffer_rsrc_t seq_rsrc =
       BASE == B_SEQ && e.tab.loc != LOC_LDS ? make_rsrc(e.tab.g, e.tab.count * 8) : make_rsrc(nullptr, 0);
-  constexpr u32 kRowsPerIter = kBlockThreads * 2 * kUnroll4;
+  constexpr u32 kUnrollHere = BASE == B_SEQ ? 2 * kUnroll4 : kUnroll4;  // copies: more loads in flight
+  constexpr u32 kRowsPerIter = kBlockThreads * 2 * kUnrollHere;
   const u32 whole = pairs / kRowsPerIter * kRowsPerIter;  // whole iterations: no clamps, no store predicates
   auto iteration = [&](u32 base, auto tag) {
     constexpr bool PARTIAL = decltype(tag)::value;
-    u64x2 v[kUnroll4];
+    u64x2 v[kUnrollHere];
 #pragma unroll
-    for (u32 u = 0; u < kUnroll4; u++) {
+    for (u32 u = 0; u < kUnrollHere; u++) {
       const u32 i = base + (u * kBlockThreads + tid) * 2;
       v[u] = eval_dbl2_base<BASE, TAB_LDS>(e, PARTIAL ? (i < pairs ? i : pairs - 2) : i, seq_rsrc);
     }
 #pragma unroll
-    for (u32 u = 0; u < kUnroll4; u++) {
+    for (u32 u = 0; u < kUnrollHere; u++) {
       const u32 i = base + (u * kBlockThreads + tid) * 2;
       if (!PARTIAL || i < pairs) __builtin_nontemporal_store(v[u], reinterpret_cast<u64x2*>(dst + i));
     }
