@@ -840,17 +840,36 @@ __device__ __forceinline__ void walker_finish(const WalkEnd& w, const Ctx& c, co
     const u32 first = w.W > 64 ? w.W - 64 : 0;
     const u32 skip = pos > first ? pos - first : 0;  // lanes in front of the tail
     const u32 tail_words = w.W - first - skip;
-    u32 v = 0, shift = 0, produced = 0;
-    for (u32 bi = 0; bi < tail_words * 4; bi++) {
-      const u32 wv = __builtin_amdgcn_readlane(w.tail_word, skip + (bi >> 2));
-      const u32 ch = (wv >> ((bi & 3) * 8)) & 0xFF;
-      v += (ch & 127) << (shift & 31);
-      shift += 7;
-      if (ch & 128) {
-        if (produced < 32 && lane == 0) lds_st32(tail_off + 4 * produced, v);
-        produced++;
-        v = 0;
-        shift = 0;
+    // Lane l holds word first + l; the tail is lanes [skip, skip + tail_words). A byte with its top
+    // bit set ends a value. All values are decoded at once: ballots over the four byte positions
+    // give every terminator its value index, and a value (at most five bytes) lies inside the
+    // 8-byte window {previous lane's word, own word}. Words outside the tail count as all
+    // terminators, which bounds the first value on the left.
+    const bool mine = lane >= skip && lane < skip + tail_words;
+    const u32 cur = mine ? w.tail_word : 0x80808080u;
+    const u32 left = __builtin_amdgcn_ds_bpermute(((lane ? lane : 1) - 1) << 2, cur);
+    const u64 win = ((u64)cur << 32) | (lane ? left : 0x80808080u);
+    u32 idx = 0, produced = 0;
+#pragma unroll
+    for (u32 j = 0; j < 4; j++) {
+      const u64 t = __builtin_amdgcn_ballot_w64(mine && ((cur >> (8 * j + 7)) & 1));
+      idx += __builtin_amdgcn_mbcnt_hi((u32)(t >> 32), __builtin_amdgcn_mbcnt_lo((u32)t, 0u));  // in the lanes below
+      produced += (u32)__popcll(t);
+    }
+#pragma unroll
+    for (u32 j = 0; j < 4; j++) {
+      if (mine && ((cur >> (8 * j + 7)) & 1)) {
+        const u32 p8 = 4 + j;  // the terminator's byte inside the window
+        const u32 c1 = ((u32)(win >> (8 * (p8 - 1) + 7)) & 1) ^ 1;
+        const u32 c2 = c1 & (((u32)(win >> (8 * (p8 - 2) + 7)) & 1) ^ 1);
+        const u32 c3 = c2 & (((u32)(win >> (8 * (p8 - 3) + 7)) & 1) ^ 1);
+        const u32 c4 = c3 & (((u32)(win >> (8 * (p8 - 4) + 7)) & 1) ^ 1);
+        const u32 len = 1 + c1 + c2 + c3 + c4;
+        const u64 f = (win >> (8 * (p8 + 1 - len))) & ((1ull << (8 * len)) - 1);
+        const u32 v = ((u32)f & 0x7F) | (((u32)(f >> 8) & 0x7F) << 7) | (((u32)(f >> 16) & 0x7F) << 14) |
+                      (((u32)(f >> 24) & 0x7F) << 21) | (((u32)(f >> 32) & 0x7F) << 28);
+        if (idx < 32) lds_st32(tail_off + 4 * idx, v);
+        idx++;
       }
     }
     if ((produced != expect || pos < first) && lane == 0) raise(c, ST_BP_TAIL);
