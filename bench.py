@@ -99,6 +99,7 @@ def main():
     ap.add_argument("--cpu-sample-chunks", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--verify", action="store_true", help="compare a sample of chunks with the oracle")
+    ap.add_argument("--verify-stride", type=int, default=257, help="with --verify: check every N-th chunk")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
     ap.add_argument("--one-device", action="store_true",
                     help="rehearsal on a one-GPU box: every rank uses cuda:0 (needs --backend gloo)")
@@ -171,7 +172,7 @@ def main():
             pos = 0
             for i, (o, n) in enumerate(r.chunks):
                 rows = r.infos[i].tuple_count
-                if i % 257 == 0:
+                if i % args.verify_stride == 0:
                     want = pyoracle.decode_chunk(r.image[o:o + n])
                     assert np.array_equal(host[pos:pos + rows].view(np.uint8), want.view(np.uint8)), f"chunk {i} differs"
                 pos += rows
