@@ -1853,6 +1853,94 @@ __device__ __forceinline__ void mat_dbl2(const Ctx& c, const DblEval& e, u64* __
   if (tid < count - pairs) dst[pairs + tid] = eval_dbl<BASE, GEN, GEN, PS_GEN>(e, pairs + tid, bad);
 }
 
+// PSEUDODECIMAL whose digits and exponents are both run-length encoded (bare RLE pipes), four
+// consecutive rows per lane: the rows share one word of each bitmap (run starts of the exponents,
+// exception flags, and - up to a word boundary - run starts of the digits), so each of the three
+// rank lookups is made once and advanced by flag bits for the other rows. Results are those of
+// eval_dbl<B_PSEUDO> row by row (double/Pseudodecimal.cpp:424-436).
+// EXP_LDS / DIG_LDS: where the run-value tables sit, fixed at compile time so that a lane's loads
+// are not separated by location tests.
+template <bool EXP_LDS, bool DIG_LDS>
+__device__ __forceinline__ void mat_pseudo_rle4(const Ctx& c, const DblEval& e, u64* __restrict__ dst, u32 count) {
+  const u32 tid = threadIdx.x;
+  const u32 quads = count & ~3u;
+  u32 bad = 0;
+  const u32 e_last = e.ib.tab.count - 1, d_last = e.k0 ? e.ia.tab.count - 1 : 0;
+  const u32 di_last = e.k0 ? e.k0 - 1 : 0;
+  // two quads per lane and iteration: the table loads of both (the digit values may sit in the
+  // chunk's scratch slice in global memory) are in flight together
+  auto quad = [&](u32 first, u64 (&out)[4]) -> u32 {
+    const u32 i = first < quads ? first : quads - 4;  // lanes past the end repeat the last quad
+    const u32 w = i >> 6, p = i & 63;
+    // exponents: run index of row i + k = starts at or before it, minus one
+    const u64 se = lds64(e.ib.rk.bits_off + 8 * w);
+    const u32 ne = lds32(e.ib.rk.rank_off + 4 * w) + (u32)__popcll(se & ((2ull << p) - 1));
+    const u32 fe = (u32)((se >> p) >> 1);  // start flags of rows i+1..
+    // exceptions strictly before row i + k
+    const u64 sx = lds64(e.rk.bits_off + 8 * w);
+    const u32 nx = lds32(e.rk.rank_off + 4 * w) + (u32)__popcll(sx & ((1ull << p) - 1));
+    const u32 fx = (u32)(sx >> p) & 15;
+    u32 ex[4], xr[4], di[4];
+#pragma unroll
+    for (u32 k = 0; k < 4; k++) {
+      const u32 n = ne + (u32)__builtin_popcount(fe & ((1u << k) - 1));
+      u32 r = n ? n - 1 : 0;
+      r = r < e_last ? r : e_last;
+      ex[k] = EXP_LDS ? lds32(e.ib.tab.lds + 4 * r) : ldg32(e.ib.tab.g + 4ull * r);
+      xr[k] = nx + (u32)__builtin_popcount(fx & ((1u << k) - 1));
+      const u32 d = i + k - xr[k];
+      di[k] = d < di_last ? d : di_last;
+    }
+    // digits: rank lookup for the first digit index, flag bits for the (at most three) following ones
+    u32 dg[4] = {0, 0, 0, 0};
+    if (e.k0) {
+      const u32 wd = di[0] >> 6, pd = di[0] & 63;
+      const u64 s0 = lds64(e.ia.rk.bits_off + 8 * wd), s1 = lds64(e.ia.rk.bits_off + 8 * wd + 8);
+      const u32 nd = lds32(e.ia.rk.rank_off + 4 * wd) + (u32)__popcll(s0 & ((2ull << pd) - 1));
+      const u32 fd = (u32)(((s0 >> pd) >> 1) | ((s1 << (63 - pd))));  // start flags of digits di[0]+1..
+#pragma unroll
+      for (u32 k = 0; k < 4; k++) {
+        const u32 ahead = di[k] - di[0];  // 0..3
+        const u32 n = nd + (u32)__builtin_popcount(fd & ((1u << ahead) - 1));
+        u32 r = n ? n - 1 : 0;
+        r = r < d_last ? r : d_last;
+        dg[k] = DIG_LDS ? lds32(e.ia.tab.lds + 4 * r) : ldg32(e.ia.tab.g + 4ull * r);
+      }
+    }
+#pragma unroll
+    for (u32 k = 0; k < 4; k++) {
+      u32 idx = ex[k] & btrfmt::DEC_INDEX_MASK;
+      bad |= (ex[k] != btrfmt::DEC_EXCEPTION_CODE && idx > btrfmt::DEC_MAX_EXPONENT) ? 2u : 0u;
+      idx = idx > btrfmt::DEC_MAX_EXPONENT ? btrfmt::DEC_MAX_EXPONENT : idx;
+      const u64 fbits = ((u64)(u32)__builtin_amdgcn_ds_bpermute(idx << 2, e.frac_hi) << 32) |
+                        (u32)__builtin_amdgcn_ds_bpermute(idx << 2, e.frac_lo);
+      out[k] = (u64)__double_as_longlong((double)(int)dg[k] * __longlong_as_double((long long)fbits));
+      if (ex[k] == btrfmt::DEC_EXCEPTION_CODE) {
+        const u32 pi = xr[k] < e.tab.count ? xr[k] : e.tab.count - 1;
+        out[k] = e.tab.count ? tab_ld64(e.tab, pi) : 0;
+      }
+    }
+    return i;
+  };
+  auto put = [&](u32 first, u32 i, const u64 (&out)[4]) {
+    if (first < quads) {
+      u64x2 lo, hi;
+      lo.x = out[0], lo.y = out[1], hi.x = out[2], hi.y = out[3];
+      __builtin_nontemporal_store(lo, reinterpret_cast<u64x2*>(dst + i));
+      __builtin_nontemporal_store(hi, reinterpret_cast<u64x2*>(dst + i + 2));
+    }
+  };
+  for (u32 base = 0; base < quads; base += kBlockThreads * 8) {
+    u64 oa[4], ob[4];
+    const u32 fa = base + tid * 4, fb = fa + kBlockThreads * 4;
+    const u32 ia = quad(fa, oa), ib = quad(fb, ob);
+    put(fa, ia, oa);
+    put(fb, ib, ob);
+  }
+  if (tid < count - quads) dst[quads + tid] = eval_dbl<B_PSEUDO, B_RLE, B_RLE, PS_NONE>(e, quads + tid, bad);
+  report(c, bad);
+}
+
 // Whether a double root can take the two-rows-per-lane path into a 16-byte aligned output.
 __device__ __forceinline__ bool wide_rows_dbl(const DblEval& e, const Tab& out, u32 count) {
   if (out.loc == LOC_LDS || (reinterpret_cast<u64>(out.g) & 15) != 0 || count < 2) return false;
@@ -1935,8 +2023,24 @@ __device__ __forceinline__ void materialize(const Ctx& c, u32 pipe_id, u32 seq_i
       case B_PSEUDO:
         if (e.ib.base == B_BP && (e.ia.base == B_BP || e.k0 == 0) && bare)
           mat_dbl<B_PSEUDO, B_BP, B_BP, PS_NONE>(c, e, out, count);
-        else if (e.ib.base == B_RLE && (e.ia.base == B_RLE || e.k0 == 0) && bare)
-          mat_dbl<B_PSEUDO, B_RLE, B_RLE, PS_NONE>(c, e, out, count);
+        else if (e.ib.base == B_RLE && (e.ia.base == B_RLE || e.k0 == 0) && bare) {
+          if (out.loc != LOC_LDS && (reinterpret_cast<u64>(out.g) & 15) == 0 && count >= 4 && e.ib.tab.count > 0 &&
+              (e.k0 == 0 || e.ia.tab.count > 0))
+          {
+            u64* d = reinterpret_cast<u64*>(const_cast<u8*>(out.g));
+            const bool el = e.ib.tab.loc == LOC_LDS, dl = e.k0 == 0 || e.ia.tab.loc == LOC_LDS;
+            if (el && dl)
+              mat_pseudo_rle4<true, true>(c, e, d, count);
+            else if (el)
+              mat_pseudo_rle4<true, false>(c, e, d, count);
+            else if (dl)
+              mat_pseudo_rle4<false, true>(c, e, d, count);
+            else
+              mat_pseudo_rle4<false, false>(c, e, d, count);
+          }
+          else
+            mat_dbl<B_PSEUDO, B_RLE, B_RLE, PS_NONE>(c, e, out, count);
+        }
         else if (e.ib.base == B_RLE && e.ia.base == B_BP && bare)
           mat_dbl<B_PSEUDO, B_BP, B_RLE, PS_NONE>(c, e, out, count);
         else
