@@ -2548,6 +2548,32 @@ __device__ __forceinline__ void bitmap_eq(const Ctx& c, const Step& s) {
     }
     return;
   }
+  if (e.base == B_RLE && e.n_post == 0 && e.tab.count > 0) {
+    // a word of the result per thread: the runs that start inside the word (bits of the run-start
+    // bitmap) cut it into stretches, and a stretch is all ones when its run's value matches
+    const u32 last = e.tab.count - 1;
+    const u32 need = (nbits + 63) / 64 < words ? (nbits + 63) / 64 : words;
+    for (u32 w = threadIdx.x; w < need; w += THREADS) {
+      u64 rest = lds64(e.rk.bits_off + 8 * w);
+      const u32 n = lds32(e.rk.rank_off + 4 * w);  // runs that start before this word
+      u32 r = n ? n - 1 : 0, k = 0, pos = 0;
+      u64 out = 0;
+      for (;;) {
+        const bool match = tab_ld32(e.tab, r < last ? r : last) == value;
+        const u32 nxt = rest ? (u32)__builtin_ctzll(rest) : 64u;
+        if (match && nxt > pos) out |= (nxt == 64 ? ~0ull : (1ull << nxt) - 1) & ~((1ull << pos) - 1);
+        if (nxt == 64) break;
+        r = n + k;  // the run that starts at nxt: rank_le - 1
+        k++;
+        pos = nxt;
+        rest &= rest - 1;
+      }
+      const u32 left = nbits - 64 * w;
+      if (left < 64) out &= (1ull << left) - 1;
+      lds_st64(bits_off + 8 * w, out);
+    }
+    return;
+  }
   u32 bad = 0;
   constexpr u32 kEqUnroll = 4;  // independent rows in flight per lane: the lookups are LDS-latency chains
   for (u32 base = 0; base < nbits; base += THREADS * kEqUnroll) {
