@@ -1867,6 +1867,8 @@ __device__ __forceinline__ void mat_pseudo_rle4(const Ctx& c, const DblEval& e, 
   u32 bad = 0;
   const u32 e_last = e.ib.tab.count - 1, d_last = e.k0 ? e.ia.tab.count - 1 : 0;
   const u32 di_last = e.k0 ? e.k0 - 1 : 0;
+  const bool patches_lds = e.tab.loc == LOC_LDS;
+  const __amdgpu_buffer_rsrc_t rsrc_p = make_rsrc(patches_lds ? nullptr : e.tab.g, patches_lds ? 0 : e.tab.count * 8);
   // two quads per lane and iteration: the table loads of both (the digit values may sit in the
   // chunk's scratch slice in global memory) are in flight together
   auto quad = [&](u32 first, u64 (&out)[4]) -> u32 {
@@ -1890,6 +1892,19 @@ __device__ __forceinline__ void mat_pseudo_rle4(const Ctx& c, const DblEval& e, 
       xr[k] = nx + (u32)__builtin_popcount(fx & ((1u << k) - 1));
       const u32 d = i + k - xr[k];
       di[k] = d < di_last ? d : di_last;
+    }
+    // patch candidates for all four rows, loaded before anything waits for them (an index past the
+    // last patch reads 0 through the descriptor); a row takes its candidate if its exponent says so
+    u64 pw[4];
+    if (patches_lds) {
+#pragma unroll
+      for (u32 k = 0; k < 4; k++) pw[k] = xr[k] < e.tab.count ? lds64(e.tab.lds + 8 * xr[k]) : 0;
+    } else {
+#pragma unroll
+      for (u32 k = 0; k < 4; k++) {
+        const u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(rsrc_p, xr[k] * 8, 0, 0);
+        pw[k] = ((u64)t.y << 32) | t.x;
+      }
     }
     // digits: rank lookup for the first digit index, flag bits for the (at most three) following ones
     u32 dg[4] = {0, 0, 0, 0};
@@ -1915,10 +1930,7 @@ __device__ __forceinline__ void mat_pseudo_rle4(const Ctx& c, const DblEval& e, 
       const u64 fbits = ((u64)(u32)__builtin_amdgcn_ds_bpermute(idx << 2, e.frac_hi) << 32) |
                         (u32)__builtin_amdgcn_ds_bpermute(idx << 2, e.frac_lo);
       out[k] = (u64)__double_as_longlong((double)(int)dg[k] * __longlong_as_double((long long)fbits));
-      if (ex[k] == btrfmt::DEC_EXCEPTION_CODE) {
-        const u32 pi = xr[k] < e.tab.count ? xr[k] : e.tab.count - 1;
-        out[k] = e.tab.count ? tab_ld64(e.tab, pi) : 0;
-      }
+      if (ex[k] == btrfmt::DEC_EXCEPTION_CODE) out[k] = pw[k];
     }
     return i;
   };

@@ -15,6 +15,7 @@
 #include "plan_builder.h"
 
 #include <algorithm>
+#include <functional>
 #include <cstring>
 
 #include "btr_format.h"
@@ -711,6 +712,78 @@ void build_program(const ColumnSource& src, BuiltProgram& out) {
   };
   const std::vector<Seq> unplaced = bld.seqs;
   place_tables();
+  if (kernel_is_generic(kernel) && !bld.transient.empty() && bld.seqs[bld.transient[0]].must_lds == 2) {
+    // The region shared by the run-length tables is free once the last of them has been scanned.
+    // A value table that found no room in LDS and is read by nothing but the root step can be
+    // filled right before the root step instead of where its node was parsed, and then lives in
+    // that region: the root step gathers from LDS instead of the scratch slice.
+    const uint32_t region_off = bld.seqs[bld.transient[0]].off;
+    uint64_t region_bytes = 0;
+    for (uint32_t id : bld.transient) region_bytes = std::max<uint64_t>(region_bytes, align_up(bld.seqs[id].count * bld.seqs[id].esize, 16));
+    auto is_transient = [&](uint32_t id) { return std::find(bld.transient.begin(), bld.transient.end(), id) != bld.transient.end(); };
+    std::function<void(uint32_t, std::vector<uint32_t>&)> reads = [&](uint32_t pipe, std::vector<uint32_t>& out) {
+      if (pipe == NONE) return;
+      const Pipe& pp = bld.pipes[pipe];
+      auto seq = [&](uint32_t id) {
+        if (id != NONE) out.push_back(id);
+      };
+      switch (pp.base) {
+        case B_SEQ: seq(pp.a[0]); break;
+        case B_BP:
+        case B_DBP: seq(pp.a[2]), seq(pp.a[4]); break;
+        case B_RLE: seq(pp.a[0]), seq(pp.a[1]), seq(pp.a[2]); break;
+        case B_FREQ: seq(pp.a[2]), seq(pp.a[3]), seq(pp.a[4]); break;
+        case B_DICTD: reads(pp.a[0], out), seq(pp.a[1]); break;
+        case B_PSEUDO: reads(pp.a[0], out), reads(pp.a[1], out), seq(pp.a[2]), seq(pp.a[3]), seq(pp.a[4]); break;
+        default: break;
+      }
+      for (int k = 0; k < pp.n_post; k++)
+        if (pp.post[k].type == POST_DICT) seq(pp.post[k].arg);
+    };
+    size_t root_idx = bld.steps.size();
+    for (size_t k = 0; k < bld.steps.size(); k++)
+      if (bld.steps[k].kind == S_MATERIALIZE && bld.steps[k].a[1] == dst) root_idx = k;
+    uint32_t best = NONE;
+    size_t best_step = 0;
+    for (uint32_t id = 0; id < bld.seqs.size() && root_idx < bld.steps.size(); id++) {
+      const Seq& sq = bld.seqs[id];
+      const uint64_t bytes = align_up(sq.count * sq.esize, 16);
+      if (sq.loc != LOC_SCRATCH || bytes == 0 || bytes > region_bytes) continue;
+      if (best != NONE && bytes <= align_up(bld.seqs[best].count * bld.seqs[best].esize, 16)) continue;
+      size_t producer = bld.steps.size(), producers = 0;
+      bool movable = true;
+      for (size_t k = 0; k < bld.steps.size(); k++) {
+        const Step& st = bld.steps[k];
+        if (st.kind == S_MATERIALIZE && st.a[1] == id) {
+          producer = k;
+          producers++;
+          continue;
+        }
+        if (st.kind == S_PFOR_DECODE && st.a[4] == id) movable = false;
+        if (k == root_idx) continue;
+        std::vector<uint32_t> used;
+        if (st.kind == S_MATERIALIZE || st.kind == S_BITMAP_EQ) reads(st.a[0], used);
+        if (st.kind == S_BITMAP_STARTS) used.push_back(st.a[0]);
+        if (std::find(used.begin(), used.end(), id) != used.end()) movable = false;
+      }
+      if (!movable || producers != 1 || producer > root_idx) continue;
+      std::vector<uint32_t> inputs;
+      reads(bld.steps[producer].a[0], inputs);
+      if (std::any_of(inputs.begin(), inputs.end(), is_transient)) continue;
+      best = id;
+      best_step = producer;
+    }
+    if (best != NONE) {
+      const Step moved = bld.steps[best_step];
+      bld.steps.erase(bld.steps.begin() + best_step);
+      bld.steps.insert(bld.steps.begin() + (root_idx - 1), moved);  // root_idx shifted down by the erase
+      bld.seqs[best].loc = LOC_LDS;
+      bld.seqs[best].off = region_off;
+      scratch = 0;  // the scratch slice ends behind the last table left in it
+      for (const Seq& sq : bld.seqs)
+        if (sq.loc == LOC_SCRATCH) scratch = std::max<uint64_t>(scratch, sq.off + align_up(sq.count * sq.esize, 16));
+    }
+  }
   if (!kernel_is_generic(kernel) && kernel != KERNEL_STREAM_PSEUDO && bld.steps.back().a[3] != NONE) {
     // A stream kernel runs at most four 512-thread workgroups per CU, fewer when LDS runs out. The
     // walker's jump table only speeds up streams whose group lengths vary: when all groups of this
