@@ -546,10 +546,11 @@ __device__ __forceinline__ u64 eval_dbl(const DblEval& e, u32 i, u32& bad) {
     const u64 fbits = ((u64)(u32)__builtin_amdgcn_ds_bpermute(idx << 2, e.frac_hi) << 32) |
                       (u32)__builtin_amdgcn_ds_bpermute(idx << 2, e.frac_lo);
     u64 r = (u64)__double_as_longlong((double)digits * __longlong_as_double((long long)fbits));
-    if (ex == btrfmt::DEC_EXCEPTION_CODE) {
-      const u32 pi = xr < e.tab.count ? xr : e.tab.count - 1;
-      r = e.tab.count ? tab_ld64(e.tab, pi) : 0;
-    }
+    // the patch candidate is loaded for every row: a load inside the rare divergent branch would
+    // expose its whole memory latency whenever any lane of the wave takes it
+    const u32 pi = xr < e.tab.count ? xr : e.tab.count - 1;
+    const u64 patch = e.tab.count ? tab_ld64(e.tab, pi) : 0;
+    if (ex == btrfmt::DEC_EXCEPTION_CODE) r = patch;
     return r;
   }
   if (BASE == B_DBP) {
