@@ -2630,24 +2630,41 @@ __device__ __forceinline__ void bitmap_rank(const Ctx& c, const Step& s) {
 }
 
 // extern/RoaringBitmap.cpp:32-53: one byte per row, 1 = valid.
+template <u32 THREADS = kBlockThreads>
 __device__ __forceinline__ void write_nullmap(const Ctx& c, const Step& s) {
   const u32 type = uniform(s.a[0]), n = uniform(s.a[3]);
   const u32 bits_off = uniform(s.a[1]) == NONE ? 0 : seq_lds(c, uniform(s.a[1]));
-  for (u32 i = threadIdx.x; i < n; i += kBlockThreads) {
-    u8 v;
-    if (type == btrfmt::NM_ALLONES) {
-      v = 1;
-    } else if (type == btrfmt::NM_ALLZEROS) {
-      v = 0;
-    } else {
-      const u32 bit = (u32)(lds64(bits_off + 8 * (i >> 6)) >> (i & 63)) & 1;
-      v = (u8)(type == btrfmt::NM_REGULAR ? bit : bit ^ 1);
-    }
-    c.nullmap[i] = v;
+  if (type == btrfmt::NM_ALLONES || type == btrfmt::NM_ALLZEROS) {
+    // constant map: 16 bytes per lane behind an aligned head
+    const u32 fill = type == btrfmt::NM_ALLONES ? 0x01010101u : 0u;
+    const u32 head = (u32)((16 - (reinterpret_cast<u64>(c.nullmap) & 15)) & 15);
+    const u32 h = head < n ? head : n;
+    const u32 body = (n - h) / 16;
+    u32x4 v;
+    v.x = v.y = v.z = v.w = fill;
+    for (u32 q = threadIdx.x; q < body; q += THREADS)
+      __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(c.nullmap + h + 16 * q));
+    for (u32 i = threadIdx.x; i < h; i += THREADS) c.nullmap[i] = (u8)fill;
+    for (u32 i = h + 16 * body + threadIdx.x; i < n; i += THREADS) c.nullmap[i] = (u8)fill;
+    return;
+  }
+  for (u32 i = threadIdx.x; i < n; i += THREADS) {
+    const u32 bit = (u32)(lds64(bits_off + 8 * (i >> 6)) >> (i & 63)) & 1;
+    c.nullmap[i] = (u8)(type == btrfmt::NM_REGULAR ? bit : bit ^ 1);
   }
 }
 
-// Copies the work item's program into LDS at byte offset BASE and sets up the workgroup context.
+// The streamed root of a stream kernel's program: the last step, or the one in front of a
+// trailing constant-nullmap step.
+__device__ __forceinline__ u32 stream_root_index(const Ctx& c, const ProgramHeader& hdr) {
+  const u32 last = hdr.n_steps - 1;
+  return uniform(step_at(c, last).kind) == S_NULLMAP ? last - 1 : last;
+}
+template <u32 THREADS>
+__device__ __forceinline__ void stream_trailing_nullmap(const Ctx& c, const ProgramHeader& hdr, u32 root_idx) {
+  if (root_idx + 1 < hdr.n_steps) write_nullmap<THREADS>(c, step_at(c, root_idx + 1));
+}
+
 template <u32 THREADS, u32 BASE>
 __device__ __forceinline__ ProgramHeader load_program(const WorkItem& it, u32 item, const u8* __restrict__ programs,
                                                       u32* __restrict__ status, Ctx& c) {
@@ -2709,17 +2726,19 @@ __device__ __forceinline__ void stream_block(const WorkItem* __restrict__ items,
   const WorkItem it = items[item];
   Ctx c;
   const ProgramHeader hdr = load_program<kStreamThreads, kStreamProgBase>(it, item, programs, status, c);
-  for (u32 s = 0; s + 1 < hdr.n_steps; s++) {  // dictionary copies: a bare source sequence -> LDS
+  const u32 root_idx = stream_root_index(c, hdr);
+  for (u32 s = 0; s < root_idx; s++) {  // dictionary copies: a bare source sequence -> LDS
     const Step& st = step_at(c, s);
     const Tab from = resolve_tab(c, uniform(pipe_at(c, uniform(st.a[0])).a[0]));
     const Tab to = resolve_tab(c, uniform(st.a[1]));
     copy_to_lds<kStreamThreads>(to.lds, from.g, to.count * to.esize);
   }
   __syncthreads();
-  const Step& root = step_at(c, hdr.n_steps - 1);
+  const Step& root = step_at(c, root_idx);
   const u32 pipe_id = uniform(root.a[0]);
   const IntEval e = resolve_int(c, pipe_id);
   stream_int_bp<PS>(c, pipe_at(c, pipe_id), e, reinterpret_cast<u32*>(c.dst), jump_scratch(c, root));
+  stream_trailing_nullmap<kStreamThreads>(c, hdr, root_idx);
 }
 
 // DICT(BP) double chunks: [dictionary copy into LDS] + streamed root.
@@ -2730,7 +2749,8 @@ __device__ __forceinline__ void stream_dictd_block(const WorkItem* __restrict__ 
   Ctx c;
   stamp(it, 0);
   const ProgramHeader hdr = load_program<kDictdThreads, kStreamProgBase>(it, item, programs, status, c);
-  for (u32 s = 0; s + 1 < hdr.n_steps; s++) {
+  const u32 root_idx = stream_root_index(c, hdr);
+  for (u32 s = 0; s < root_idx; s++) {
     const Step& st = step_at(c, s);
     const Tab from = resolve_tab(c, uniform(pipe_at(c, uniform(st.a[0])).a[0]));
     const Tab to = resolve_tab(c, uniform(st.a[1]));
@@ -2738,8 +2758,9 @@ __device__ __forceinline__ void stream_dictd_block(const WorkItem* __restrict__ 
   }
   __syncthreads();
   stamp(it, 1);
-  const Step& root = step_at(c, hdr.n_steps - 1);
+  const Step& root = step_at(c, root_idx);
   stream_dictd(c, pipe_at(c, uniform(root.a[0])), reinterpret_cast<u64*>(c.dst), jump_scratch(c, root));
+  stream_trailing_nullmap<kDictdThreads>(c, hdr, root_idx);
   stamp(it, 2);
 }
 
@@ -2753,7 +2774,8 @@ __device__ __forceinline__ void stream_pseudo_block(const WorkItem* __restrict__
   stamp(it, 0);
   const ProgramHeader hdr = load_program<kStreamThreads, kStreamProgBase>(it, item, programs, status, c);
   stamp(it, 1);
-  const Step& root = step_at(c, hdr.n_steps - 1);
+  const u32 root_idx = stream_root_index(c, hdr);
+  const Step& root = step_at(c, root_idx);
   const Pipe& rp = pipe_at(c, uniform(root.a[0]));
   const Pipe& pd = pipe_at(c, uniform(rp.a[0]));
   const Pipe& pe = pipe_at(c, uniform(rp.a[1]));
@@ -2773,6 +2795,7 @@ __device__ __forceinline__ void stream_pseudo_block(const WorkItem* __restrict__
   __syncthreads();
   stamp(it, 4);
   stream_pseudo(c, rp, pd, pe, rk, reinterpret_cast<u64*>(c.dst), frac_off, jump_off);
+  stream_trailing_nullmap<kStreamThreads>(c, hdr, root_idx);
   stamp(it, 5);
 }
 

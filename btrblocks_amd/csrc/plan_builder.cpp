@@ -572,8 +572,10 @@ void build_program(const ColumnSource& src, BuiltProgram& out) {
   // LDS, and its group index is built while decoding instead of in a separate pass.
   {
     const Pipe& rp = bld.pipes[root];
+    // a byte-per-row nullmap that is one constant is written by the stream kernels themselves
+    const bool const_nullmap = !src.want_nullmap || src.nullmap_type == NM_ALLONES || src.nullmap_type == NM_ALLZEROS;
     bool eligible = src.column_type == COL_INTEGER && rp.base == B_BP && rp.n_post <= 1 &&
-                    !src.want_nullmap && bld.bp_steps.size() == 1 && n > 0;
+                    const_nullmap && bld.bp_steps.size() == 1 && n > 0;
     for (const Step& st : bld.steps)
       eligible = eligible && st.kind == S_MATERIALIZE && bld.pipes[st.a[0]].base == B_SEQ &&
                  bld.pipes[st.a[0]].n_post == 0 && bld.seqs[st.a[1]].esize == 4;
@@ -587,7 +589,7 @@ void build_program(const ColumnSource& src, BuiltProgram& out) {
         kernel = KERNEL_STREAM_ADD;
       else
         kernel = KERNEL_STREAM_DICT_LDS;  // corrected below once table placement is known
-    } else if (src.column_type == COL_DOUBLE && rp.base == B_DICTD && !src.want_nullmap && n > 0 &&
+    } else if (src.column_type == COL_DOUBLE && rp.base == B_DICTD && const_nullmap && n > 0 &&
                bld.bp_steps.size() == 1 && bld.pipes[rp.a[0]].base == B_BP && bld.pipes[rp.a[0]].n_post == 0 &&
                bld.seqs[rp.a[1]].count > 0 &&
                std::all_of(bld.steps.begin(), bld.steps.end(), [&](const Step& st) {
@@ -598,7 +600,7 @@ void build_program(const ColumnSource& src, BuiltProgram& out) {
       bld.add_step(S_STREAM_ROOT, root, dst);
       prog_base = kStreamProgBase;
       kernel = KERNEL_STREAM_DICTD;
-    } else if (src.column_type == COL_DOUBLE && rp.base == B_PSEUDO && rp.a[0] != NONE && !src.want_nullmap &&
+    } else if (src.column_type == COL_DOUBLE && rp.base == B_PSEUDO && rp.a[0] != NONE && const_nullmap &&
                n > 0 && n / 64 + 1 <= 4096 && bld.bp_steps.size() == 2 && bld.steps.size() == 3 &&
                bld.pipes[rp.a[0]].base == B_BP && bld.pipes[rp.a[0]].n_post == 0 &&
                bld.pipes[rp.a[1]].base == B_BP && bld.pipes[rp.a[1]].n_post == 0 &&
@@ -784,7 +786,9 @@ void build_program(const ColumnSource& src, BuiltProgram& out) {
         if (sq.loc == LOC_SCRATCH) scratch = std::max<uint64_t>(scratch, sq.off + align_up(sq.count * sq.esize, 16));
     }
   }
-  if (!kernel_is_generic(kernel) && kernel != KERNEL_STREAM_PSEUDO && bld.steps.back().a[3] != NONE) {
+  size_t stream_root = bld.steps.size() - 1;  // a constant-nullmap step may follow the streamed root
+  while (stream_root > 0 && bld.steps[stream_root].kind != S_STREAM_ROOT) stream_root--;
+  if (!kernel_is_generic(kernel) && kernel != KERNEL_STREAM_PSEUDO && bld.steps[stream_root].a[3] != NONE) {
     // A stream kernel runs at most four 512-thread workgroups per CU, fewer when LDS runs out. The
     // walker's jump table only speeds up streams whose group lengths vary: when all groups of this
     // stream are equally long, give it up if that lets one more workgroup share the CU.
@@ -808,10 +812,10 @@ void build_program(const ColumnSource& src, BuiltProgram& out) {
       return true;
     };
     if (per_cu(without) > per_cu(with) && equally_long()) {
-      const uint32_t jump = bld.steps.back().a[3];
+      const uint32_t jump = bld.steps[stream_root].a[3];
       bld.seqs = unplaced;
       bld.seqs[jump].count = 0;
-      bld.steps.back().a[3] = NONE;
+      bld.steps[stream_root].a[3] = NONE;
       place_tables();
     }
   }

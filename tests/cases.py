@@ -139,4 +139,9 @@ def cases():
         add(f"dbl_pseudo_n{n}", synth.double_decimal(max(n, 1), patch_fraction=0.05)[:n], "pseudodecimal(bp,bp,uncompressed)")
         add(f"dbl_dict_n{n}", synth.dictionary_values(max(n, 1), 50, dtype=np.float64)[:n], "dict(bp)")
     add("dbl_pseudo_nulls", synth.double_decimal(N), "pseudodecimal(bp,bp,uncompressed)", nullmap=synth.random_nullmap(N, 0.9))
+    # a nullmap that is not one constant sends these trees through the generic kernels
+    add("dbl_dict_nulls", synth.dictionary_values(N, 1020, dtype=np.float64), "dict(bp)", nullmap=synth.random_nullmap(N, 0.6, seed=3))
+    add("int_for_nulls", synth.int_for(N), "for(bp)", nullmap=synth.random_nullmap(N, 0.6, seed=4))
+    add("int_dict_big_nulls", _rng(15).integers(0, 2**31, N).astype(np.int32), "dict(bp)", nullmap=synth.random_nullmap(N, 0.6, seed=5))
+    add("int_dict_allnull", synth.int_dict(N), "dict(bp)", nullmap=np.zeros(N, dtype=np.uint8))
     return out
