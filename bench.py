@@ -39,6 +39,7 @@ COLUMNS = {
     "freq_dict": ("int_frequency_pool", "frequency(dict(bp))", 9),
     "pfor": ("int_outliers", "pfor", 10),
     "pseudo_rle": ("double_decimal_runs", "pseudodecimal(rle(dict(bp),bp),rle(bp,bp),uncompressed)", 11),
+    "pseudo_auto": ("double_decimal", "pseudodecimal", 4),  # children picked by the compressor: (BP, DICT(BP), raw patches)
     "dbl_dict": ("double_dict", "dict(bp)", 12),
     "dbl_rle": ("double_runs", "rle(uncompressed,bp)", 13),
     # engine ceilings: a pure fill (ONE_VALUE) and a pure copy (UNCOMPRESSED)

@@ -133,6 +133,13 @@ struct btr_gpu_plan {
   uint32_t kind_lds[KERNEL_KINDS] = {};  // dynamic LDS per launch
   uint8_t* d_scratch = nullptr;
   uint32_t* d_debug = nullptr;  // BTR_DEBUG_FLAGS & 8: kDebugSlots timestamps per work item
+  // A plan with several kernel kinds launches all but the largest on side streams (created with the
+  // plan) that fork from and join the caller's stream by events: a handful of odd chunks then
+  // decode beside the main launch instead of adding their whole latency behind it.
+  hipStream_t side[KERNEL_KINDS] = {};
+  hipEvent_t side_done[KERNEL_KINDS] = {};
+  hipEvent_t fork = nullptr;
+  uint32_t main_kind = 0;
   btr_plan_stats stats{};
   std::vector<uint32_t> h_status;
 };
@@ -214,6 +221,26 @@ btr_status finish_plan(btr_gpu_ctx* ctx, std::vector<WorkItem>& items, std::vect
         plan->stats.kernel_mask |= 1u << kind;
         plan->stats.launches++;
       }
+    size_t most = 0;
+    for (uint32_t kind = 0; kind < KERNEL_KINDS; kind++)
+      if (plan->kind_begin[kind + 1] - plan->kind_begin[kind] > most) {
+        most = plan->kind_begin[kind + 1] - plan->kind_begin[kind];
+        plan->main_kind = kind;
+      }
+    if (plan->stats.launches > 1) {
+      if ((e = hipEventCreateWithFlags(&plan->fork, hipEventDisableTiming)) != hipSuccess)
+        return cleanup(hip_fail(e, "hipEventCreate"));
+      for (uint32_t kind = 0; kind < KERNEL_KINDS; kind++) {
+        if (kind == plan->main_kind || plan->kind_begin[kind + 1] == plan->kind_begin[kind]) continue;
+        // highest priority: the few workgroups of a side launch should not queue behind the main one
+        int least = 0, greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+        if ((e = hipStreamCreateWithPriority(&plan->side[kind], hipStreamNonBlocking, greatest)) != hipSuccess)
+          return cleanup(hip_fail(e, "hipStreamCreate"));
+        if ((e = hipEventCreateWithFlags(&plan->side_done[kind], hipEventDisableTiming)) != hipSuccess)
+          return cleanup(hip_fail(e, "hipEventCreate"));
+      }
+    }
     if ((e = hipMalloc((void**)&plan->d_order, order.size() * 4)) != hipSuccess)
       return cleanup(hip_fail(e, "hipMalloc(order)"));
     if ((e = hipMemcpy(plan->d_order, order.data(), order.size() * 4, hipMemcpyHostToDevice)) != hipSuccess)
@@ -591,6 +618,14 @@ void btr_gpu_plan_destroy(btr_gpu_plan* plan) {
   if (plan->d_debug) (void)hipFree(plan->d_debug);
   if (plan->d_order) (void)hipFree(plan->d_order);
   if (plan->d_scratch) (void)hipFree(plan->d_scratch);
+  for (uint32_t kind = 0; kind < KERNEL_KINDS; kind++) {
+    if (plan->side[kind]) {
+      (void)hipStreamSynchronize(plan->side[kind]);
+      (void)hipStreamDestroy(plan->side[kind]);
+    }
+    if (plan->side_done[kind]) (void)hipEventDestroy(plan->side_done[kind]);
+  }
+  if (plan->fork) (void)hipEventDestroy(plan->fork);
   delete plan;
 }
 
@@ -618,15 +653,25 @@ btr_status btr_gpu_decode(btr_gpu_ctx* ctx, btr_gpu_plan* plan, void* hip_stream
   if (plan->n_items == 0) return BTR_OK;
   DeviceGuard guard(plan->device);
   if (!guard.ok) return fail(BTR_ERR_DEVICE, "hipSetDevice failed");
-  for (uint32_t kind = 0; kind < KERNEL_KINDS; kind++) {
+  hipStream_t stream = (hipStream_t)hip_stream;
+  auto launch = [&](uint32_t kind, hipStream_t on) {
     const size_t n = plan->kind_begin[kind + 1] - plan->kind_begin[kind];
-    if (n == 0) continue;
-    hipLaunchKernelGGL(kernel_of(kind), dim3((unsigned)n), dim3(threads_of(kind)),
-                       plan->kind_lds[kind],
-                       (hipStream_t)hip_stream, plan->d_items, plan->d_order + plan->kind_begin[kind],
-                       plan->d_programs, plan->d_status);
-    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(kernel_of(kind), dim3((unsigned)n), dim3(threads_of(kind)), plan->kind_lds[kind], on,
+                       plan->d_items, plan->d_order + plan->kind_begin[kind], plan->d_programs, plan->d_status);
+    return hipGetLastError();
+  };
+  // the small launches fork from the caller's stream first, the main one follows on the stream
+  // itself, then the stream waits for the side streams
+  if (plan->fork) HIP_TRY(hipEventRecord(plan->fork, stream));
+  for (uint32_t kind = 0; kind < KERNEL_KINDS; kind++) {
+    if (!plan->side[kind]) continue;
+    HIP_TRY(hipStreamWaitEvent(plan->side[kind], plan->fork, 0));
+    HIP_TRY(launch(kind, plan->side[kind]));
+    HIP_TRY(hipEventRecord(plan->side_done[kind], plan->side[kind]));
   }
+  HIP_TRY(launch(plan->main_kind, stream));
+  for (uint32_t kind = 0; kind < KERNEL_KINDS; kind++)
+    if (plan->side[kind]) HIP_TRY(hipStreamWaitEvent(stream, plan->side_done[kind], 0));
   return BTR_OK;
 }
 

@@ -121,6 +121,39 @@ struct Builder {
     return pipe;
   }
 
+  // Whether the stream kernel can read this exponent pipe: bare, or behind one dictionary of at
+  // most 32 entries that are all exponents the decoder accepts (0..22 and the exception code 23).
+  // The kernel reads such a dictionary from the compressed bytes itself: its LDS copy and the
+  // step that fills it are dropped.
+  bool stream_exponents(uint32_t pipe, const uint8_t* host) {
+    Pipe& p = pipes[pipe];
+    if (p.n_post == 0) return true;
+    if (p.n_post != 1 || p.post[0].type != POST_DICT) return false;
+    uint32_t dict = p.post[0].arg;
+    size_t copy_step = steps.size();
+    if (seqs[dict].loc != LOC_SRC) {
+      for (size_t k = 0; k < steps.size(); k++)
+        if (steps[k].kind == S_MATERIALIZE && steps[k].a[1] == dict) copy_step = k;
+      if (copy_step == steps.size()) return false;
+      const Pipe& from = pipes[steps[copy_step].a[0]];
+      if (from.base != B_SEQ || from.n_post != 0 || seqs[from.a[0]].loc != LOC_SRC) return false;
+      dict = from.a[0];
+    }
+    const Seq& d = seqs[dict];
+    if (d.esize != 4 || d.count == 0 || d.count > DEC_INDEX_MASK + 1) return false;
+    for (uint32_t k = 0; k < d.count; k++) {
+      uint32_t e;
+      memcpy(&e, host + d.off + 4 * k, 4);
+      if (e > DEC_EXCEPTION_CODE) return false;
+    }
+    if (copy_step != steps.size()) {
+      seqs[p.post[0].arg].count = 0;
+      steps.erase(steps.begin() + copy_step);
+      p.post[0].arg = dict;
+    }
+    return true;
+  }
+
   struct Bitmap {
     uint32_t bits, rank;
   };
@@ -601,13 +634,14 @@ void build_program(const ColumnSource& src, BuiltProgram& out) {
       prog_base = kStreamProgBase;
       kernel = KERNEL_STREAM_DICTD;
     } else if (src.column_type == COL_DOUBLE && rp.base == B_PSEUDO && rp.a[0] != NONE && const_nullmap &&
-               n > 0 && n / 64 + 1 <= 4096 && bld.bp_steps.size() == 2 && bld.steps.size() == 3 &&
+               n > 0 && n / 64 + 1 <= 4096 && bld.bp_steps.size() == 2 &&
                bld.pipes[rp.a[0]].base == B_BP && bld.pipes[rp.a[0]].n_post == 0 &&
-               bld.pipes[rp.a[1]].base == B_BP && bld.pipes[rp.a[1]].n_post == 0 &&
-               (rp.a[2] == NONE || bld.seqs[rp.a[2]].loc == LOC_SRC)) {
-      // PSEUDODECIMAL(BP,BP) with raw (or no) patches: both streams go through the LDS ring, the
-      // exponents first (exception flags into the bitmap the pipe already owns), then the digits.
-      // The program keeps the clear and rank steps; the kernel does the exponent pass in between.
+               bld.pipes[rp.a[1]].base == B_BP && (rp.a[2] == NONE || bld.seqs[rp.a[2]].loc == LOC_SRC) &&
+               bld.stream_exponents(rp.a[1], src.host) && bld.steps.size() == 3) {
+      // PSEUDODECIMAL(BP, BP or DICT(BP) with a small dictionary of valid exponents) with raw (or
+      // no) patches: both streams go through the LDS ring, the exponents first (exception flags
+      // into the bitmap the pipe already owns), then the digits. The program keeps the clear and
+      // rank steps; the kernel does the exponent pass in between.
       bld.bp_steps.clear();
       std::vector<Step> keep;
       for (const Step& st : bld.steps)
