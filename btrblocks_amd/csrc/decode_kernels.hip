@@ -1519,11 +1519,21 @@ __device__ __forceinline__ u32 select_clear(const RankView& rk, u32 words, u32 n
   return r < n ? r : n;
 }
 
+// How the streamed exponent values are read. Plain: a value is the exponent, 23 marks a patch.
+// Dictionary coded (DICT(BP) exponents, the dictionary holds at most 32 exponents, all valid -
+// checked by the plan compiler): a value is a code; the powers-of-ten table is laid out by code and
+// `exception` is the code of 23 (NONE when the dictionary has none).
+struct ExpCode {
+  u32 exception;  // stream value that marks a patch row
+  u32 need_bits;  // bits needed to represent it: narrower miniblocks hold no patch row
+  u32 codes;      // dictionary size, 0 for plain exponents
+};
+
 // Exception flags of the exponent stream: one ring pass whose unpackers turn every 64 rows into a
 // bitmap word (row i is set when its exponent is the exception code). Builds the stream-format
 // group index of the exponents on the way.
 __device__ __forceinline__ void stream_exception_bits(const Ctx& c, const Pipe& pe, const BpView& be, const RankView& rk,
-                                                      u32 words, u32 n, u32 jump_off) {
+                                                      u32 words, u32 n, u32 jump_off, const ExpCode& xc) {
   const UnpackLane u = unpack_lane();
   const u32 lane = threadIdx.x & 63;
   ring_pass(
@@ -1532,14 +1542,13 @@ __device__ __forceinline__ void stream_exception_bits(const Ctx& c, const Pipe& 
         for (u32 G = g_lo + uw; G < g_hi; G += kUnpackWaves) {
           const u64 ee = lds64(be.index_off + 8 * G);
           const u32 first = uniform((u32)ee), hdr = uniform((u32)(ee >> 32));
-          // The exception code needs five bits: a half whose two miniblocks are narrower has none.
-          // (Bits 3..7 of a width byte clear: width <= 7; then adding 3 sets bit 3 from width 5 on.)
-          const bool small = (hdr & 0xF8F8F8F8u) == 0;
-          const u32 wide = small ? (hdr + 0x03030303u) & 0x08080808u : 0x08080808u;
+          // a half (two miniblocks) narrower than the exception value holds no patch row
+          const u32 w0 = hdr >> 24, w1 = (hdr >> 16) & 0xFF, w2 = (hdr >> 8) & 0xFF, w3 = hdr & 0xFF;
+          const bool small = (hdr & 0xE0E0E0E0u) == 0;  // all widths below 32
           u64 m[2] = {0, 0};
 #pragma unroll
           for (u32 h = 0; h < 2; h++) {
-            if ((wide & (h ? 0x00000808u : 0x08080000u)) == 0) continue;
+            if ((h ? (w2 > w3 ? w2 : w3) : (w0 > w1 ? w0 : w1)) < xc.need_bits) continue;
             const u32 b = __builtin_amdgcn_ubfe(hdr, h ? u.sh_hi : u.sh_lo, 8);
             const u32 w = __builtin_amdgcn_sad_u8(hdr & (h ? u.pm_hi : u.pm_lo), 0u, first);
             const u32 bit = __umul24(u.k, b);
@@ -1548,7 +1557,7 @@ __device__ __forceinline__ void stream_exception_bits(const Ctx& c, const Pipe& 
             // width 32 (small is false then): the whole word
             const u32 x = small ? __builtin_amdgcn_ubfe(xa, 0u, b)
                                 : (__builtin_amdgcn_ubfe(xa, 0u, b) | (xa & (u32)__builtin_amdgcn_sbfe(b, 5, 1)));
-            m[h] = __builtin_amdgcn_ballot_w64(x == btrfmt::DEC_EXCEPTION_CODE);
+            m[h] = __builtin_amdgcn_ballot_w64(x == xc.exception);
           }
           if (lane == 0) {
             if (2 * G < words) lds_st64(rk.bits_off + 16 * G, m[0]);
@@ -1559,13 +1568,14 @@ __device__ __forceinline__ void stream_exception_bits(const Ctx& c, const Pipe& 
   // rows of the VariableByte tail (decoded by the walker at the end of the pass)
   if (threadIdx.x < 32) {
     const u32 i = be.rounded + threadIdx.x;
-    if (i < n && lds32(be.tail_off + 4 * threadIdx.x) == btrfmt::DEC_EXCEPTION_CODE) bitmap_or(rk.bits_off, i);
+    if (i < n && lds32(be.tail_off + 4 * threadIdx.x) == xc.exception) bitmap_or(rk.bits_off, i);
   }
   __syncthreads();
 }
 
 __device__ __forceinline__ void stream_pseudo(const Ctx& c, const Pipe& root, const Pipe& pd, const Pipe& pe,
-                                              const RankView& rk, u64* __restrict__ dst, u32 frac_off, u32 jump_off) {
+                                              const RankView& rk, u64* __restrict__ dst, u32 frac_off, u32 jump_off,
+                                              const ExpCode& xc) {
   const u32 lane = threadIdx.x & 63;
   const BpView bd = resolve_bp(c, pd), be = resolve_bp(c, pe);
   const Tab patches = resolve_tab(c, uniform(root.a[2]));
@@ -1703,7 +1713,7 @@ __device__ __forceinline__ void stream_pseudo(const Ctx& c, const Pipe& root, co
                 const u32 idx = STRAIGHT ? xv[j][h] : xv[j][h] & btrfmt::DEC_INDEX_MASK;
                 idx_max = idx_max > idx ? idx_max : idx;
                 // an exponent that is neither the exception code nor a table index: reported
-                if (!STRAIGHT && idx == btrfmt::DEC_EXCEPTION_CODE && xv[j][h] != btrfmt::DEC_EXCEPTION_CODE) exbad |= 2;
+                if (!STRAIGHT && idx == (xc.exception & btrfmt::DEC_INDEX_MASK) && xv[j][h] != xc.exception) exbad |= 2;
                 fr[j][h] = lds64(frac_off + 8 * idx);
               }
 #pragma unroll
@@ -1715,7 +1725,7 @@ __device__ __forceinline__ void stream_pseudo(const Ctx& c, const Pipe& root, co
                 u32 dv = __builtin_amdgcn_ubfe(da, 0u, dwid[j][h]);
                 if (!STRAIGHT) dv |= da & dfull[j][h];
                 const u64 r = (u64)__double_as_longlong((double)(int)dv * __longlong_as_double((long long)fr[j][h]));
-                const bool patch = xv[j][h] == btrfmt::DEC_EXCEPTION_CODE;
+                const bool patch = xv[j][h] == xc.exception;
                 out[h].x = patch ? pw[j][h].x : (u32)r;
                 out[h].y = patch ? pw[j][h].y : (u32)(r >> 32);
               }
@@ -1730,7 +1740,9 @@ __device__ __forceinline__ void stream_pseudo(const Ctx& c, const Pipe& root, co
             rows(std::false_type{});
         }
       });
-  if (idx_max > btrfmt::DEC_EXCEPTION_CODE) exbad |= 2;
+  // plain exponents: values above 23 are no table index; codes: values outside the dictionary
+  u32 codebad = 0;
+  if (xc.codes ? idx_max >= xc.codes : idx_max > btrfmt::DEC_EXCEPTION_CODE) (xc.codes ? codebad : exbad) |= 2;
   // rows behind the last one the pass could produce: digits or exponents from the tails
   const u32 end_off = c.red_off + 32;
   if (threadIdx.x == 0) lds_st32(end_off, row_end);
@@ -1749,7 +1761,7 @@ __device__ __forceinline__ void stream_pseudo(const Ctx& c, const Pipe& root, co
     const u32 xr = rank_lt(rk, i, &member);
     const u32 di = i - xr;
     u32 dv = 0;
-    if (x != btrfmt::DEC_EXCEPTION_CODE) {
+    if (x != xc.exception) {
       if (di >= bd.rounded) {
         dv = lds32(bd.tail_off + 4 * ((di - bd.rounded) & 31));
       } else {
@@ -1758,10 +1770,18 @@ __device__ __forceinline__ void stream_pseudo(const Ctx& c, const Pipe& root, co
         dv = global_extract(rsrc_d, (u32)ed, (u32)(ed >> 32), 24 - 8 * m, ~(0xFFFFFFFFu >> (8 * m)), di & 31);
       }
     }
-    u64 r = pseudo_value(dv, x, frac_off, exbad);
-    if (x == btrfmt::DEC_EXCEPTION_CODE) r = xr < patches.count ? ldg64(patches.g + 8ull * xr) : 0;
+    u32 idx = x & btrfmt::DEC_INDEX_MASK;
+    if (xc.codes) {
+      codebad |= x >= xc.codes ? 2u : 0u;
+    } else {
+      exbad |= (x != xc.exception && idx > btrfmt::DEC_MAX_EXPONENT) ? 2u : 0u;
+      idx = idx > btrfmt::DEC_MAX_EXPONENT ? btrfmt::DEC_MAX_EXPONENT : idx;
+    }
+    u64 r = (u64)__double_as_longlong((double)(int)dv * __longlong_as_double((long long)lds64(frac_off + 8 * idx)));
+    if (x == xc.exception) r = xr < patches.count ? ldg64(patches.g + 8ull * xr) : 0;
     dst[i] = r;
   }
+  if (codebad) raise(c, ST_DICT_CODE);
   if (exbad & 2) raise(c, ST_EXPONENT);
 }
 
@@ -2784,17 +2804,33 @@ __device__ __forceinline__ void stream_pseudo_block(const WorkItem* __restrict__
   rk.bits_off = seq_lds(c, uniform(rp.a[3]));
   rk.rank_off = seq_lds(c, uniform(rp.a[4]));
   const u32 n = uniform(rp.count);
-  if (threadIdx.x < 32)  // indexed by exponent & 31: entries above the largest exponent repeat it
-    lds_st64(frac_off + 8 * threadIdx.x, (u64)__double_as_longlong(kFractions[threadIdx.x < 22 ? threadIdx.x : 22]));
-  bitmap_clear<kStreamThreads>(c, step_at(c, 0));
+  // the powers-of-ten table, indexed by stream value & 31: by exponent (entries above the largest
+  // exponent repeat it) or, for dictionary-coded exponents, by code
+  ExpCode xc{btrfmt::DEC_EXCEPTION_CODE, 5, 0};
+  {
+    const u32 l = threadIdx.x & 63;
+    u32 ev = l;  // exponent behind stream value l
+    if (uniform(pe.n_post) != 0) {
+      const Tab dict = resolve_tab(c, uniform(pe.post[0].arg));
+      xc.codes = dict.count;
+      ev = l < dict.count ? tab_ld32(dict, l) : btrfmt::DEC_MAX_EXPONENT;
+      const u64 hit = __builtin_amdgcn_ballot_w64(l < dict.count && ev == btrfmt::DEC_EXCEPTION_CODE);
+      xc.exception = hit ? (u32)__builtin_ctzll(hit) : NONE;
+      xc.need_bits = !hit ? 33u : xc.exception ? 32 - (u32)__builtin_clz(xc.exception) : 0u;
+    }
+    if (threadIdx.x < 32)
+      lds_st64(frac_off + 8 * threadIdx.x,
+               (u64)__double_as_longlong(kFractions[ev < btrfmt::DEC_MAX_EXPONENT ? ev : btrfmt::DEC_MAX_EXPONENT]));
+  }
+  bitmap_clear<kStreamThreads>(c, step_at(c, root_idx - 2));
   __syncthreads();
   stamp(it, 2);
-  stream_exception_bits(c, pe, resolve_bp(c, pe), rk, n / 64 + 1, n, jump_off);
+  stream_exception_bits(c, pe, resolve_bp(c, pe), rk, n / 64 + 1, n, jump_off, xc);
   stamp(it, 3);
-  bitmap_rank<kStreamThreads>(c, step_at(c, 1));
+  bitmap_rank<kStreamThreads>(c, step_at(c, root_idx - 1));
   __syncthreads();
   stamp(it, 4);
-  stream_pseudo(c, rp, pd, pe, rk, reinterpret_cast<u64*>(c.dst), frac_off, jump_off);
+  stream_pseudo(c, rp, pd, pe, rk, reinterpret_cast<u64*>(c.dst), frac_off, jump_off, xc);
   stream_trailing_nullmap<kStreamThreads>(c, hdr, root_idx);
   stamp(it, 5);
 }
