@@ -48,7 +48,7 @@ COLUMNS = {
 }
 
 
-def build_columns(names, rows, rank, threads):
+def build_columns(names, rows, rank, threads, valid_fraction=None):
     import btrblocks_amd as B
     from btrblocks_amd import synth
     cols = []
@@ -57,7 +57,8 @@ def build_columns(names, rows, rank, threads):
         t0 = time.time()
         values = getattr(synth, gen)(rows, seed=seed + 1000 * rank)
         t1 = time.time()
-        image = B.compress_column(values, None, spec, threads=threads)
+        nullmap = None if valid_fraction is None else synth.random_nullmap(rows, valid_fraction, seed=seed + 77)
+        image = B.compress_column(values, nullmap, spec, threads=threads)
         t2 = time.time()
         cols.append({"name": name, "spec": spec, "image": image, "raw_bytes": values.nbytes,
                      "gen_s": t1 - t0, "compress_s": t2 - t1})
@@ -99,6 +100,8 @@ def main():
     ap.add_argument("--columns", default="rle,dict,for")
     ap.add_argument("--cpu-sample-chunks", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--nulls", type=float, default=None, metavar="P",
+                    help="give every column a random nullmap with a fraction P of valid rows and decode the byte-per-row maps too")
     ap.add_argument("--verify", action="store_true", help="compare a sample of chunks with the oracle")
     ap.add_argument("--verify-stride", type=int, default=257, help="with --verify: check every N-th chunk")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
@@ -130,7 +133,8 @@ def main():
     names = [n.strip() for n in args.columns.split(",") if n.strip()]
     host_threads = max(1, (os.cpu_count() or 8) // max(1, world))
     host_threads = min(host_threads, int(os.environ.get("OMP_NUM_THREADS", host_threads)) if world == 1 else host_threads)
-    cols = build_columns(names, args.rows, rank, host_threads)
+    cols = build_columns(names, args.rows, rank, host_threads, args.nulls)
+    want_nm = args.nulls is not None
 
     ctx = B.GpuContext(local_rank)
     readers = []
@@ -138,10 +142,10 @@ def main():
     for c in cols:
         t0 = time.time()
         r = B.BtrReader(c["image"], ctx=ctx)
-        r.plan(None, False)
+        r.plan(None, want_nm)
         t_plan += time.time() - t0
         readers.append(r)
-    plans = [r.plan(None, False) for r in readers]
+    plans = [r.plan(None, want_nm) for r in readers]
     stats = [p.stats for p in plans]
     out_bytes = sum(s.decoded_bytes for s in stats)
     alg_bytes = sum(s.decoded_bytes + s.needed_bytes for s in stats)

@@ -2095,12 +2095,13 @@ __device__ __forceinline__ void bitmap_clear(const Ctx& c, const Step& s) {
 }
 
 // Members of one CRoaring container (or of the whole bitmap for the u32-array form) -> bits.
+template <u32 THREADS = kBlockThreads>
 __device__ __forceinline__ void bitmap_set(const Ctx& c, const Step& s) {
   const u8* src = c.src + uniform(s.a[0]);
   const u32 bits_off = seq_lds(c, uniform(s.a[1]));
   const u32 count = uniform(s.a[2]), first = uniform(s.a[3]), nbits = uniform(s.a[4]), kind = uniform(s.a[5]);
   u32 bad = 0;
-  for (u32 k = threadIdx.x; k < count; k += kBlockThreads) {
+  for (u32 k = threadIdx.x; k < count; k += THREADS) {
     switch (kind) {
       case SET_ARRAY32: {
         const u32 r = ldg32(src + 4ull * k);
@@ -2668,21 +2669,51 @@ __device__ __forceinline__ void write_nullmap(const Ctx& c, const Step& s) {
     for (u32 i = h + 16 * body + threadIdx.x; i < n; i += THREADS) c.nullmap[i] = (u8)fill;
     return;
   }
-  for (u32 i = threadIdx.x; i < n; i += THREADS) {
+  const u32 flip = type == btrfmt::NM_REGULAR ? 0u : 0xFFFFu;
+  u32 done = 0;
+  if ((reinterpret_cast<u64>(c.nullmap) & 15) == 0) {
+    // sixteen rows per lane: four bits become four bytes by one multiply (bit k lands in byte k)
+    const u32 body = n / 16;
+    for (u32 q = threadIdx.x; q < body; q += THREADS) {
+      const u32 bits = ((lds32(bits_off + 4 * (q >> 1)) >> (16 * (q & 1))) & 0xFFFF) ^ flip;
+      u32x4 v;
+      v.x = ((bits & 15) * 0x00204081u) & 0x01010101u;
+      v.y = (((bits >> 4) & 15) * 0x00204081u) & 0x01010101u;
+      v.z = (((bits >> 8) & 15) * 0x00204081u) & 0x01010101u;
+      v.w = (((bits >> 12) & 15) * 0x00204081u) & 0x01010101u;
+      __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(c.nullmap + 16 * q));
+    }
+    done = body * 16;
+  }
+  for (u32 i = done + threadIdx.x; i < n; i += THREADS) {
     const u32 bit = (u32)(lds64(bits_off + 8 * (i >> 6)) >> (i & 63)) & 1;
-    c.nullmap[i] = (u8)(type == btrfmt::NM_REGULAR ? bit : bit ^ 1);
+    c.nullmap[i] = (u8)(bit ^ (flip & 1));
   }
 }
 
-// The streamed root of a stream kernel's program: the last step, or the one in front of a
-// trailing constant-nullmap step.
+// The streamed root of a stream kernel's program; the steps behind it build and write the nullmap.
 __device__ __forceinline__ u32 stream_root_index(const Ctx& c, const ProgramHeader& hdr) {
-  const u32 last = hdr.n_steps - 1;
-  return uniform(step_at(c, last).kind) == S_NULLMAP ? last - 1 : last;
+  u32 s = hdr.n_steps - 1;
+  while (s > 0 && uniform(step_at(c, s).kind) != S_STREAM_ROOT) s--;
+  return s;
 }
+// Nullmap steps behind the root: a constant fill, or the Roaring expansion (its bitmap and rank
+// table live in the payload ring, which is idle by now).
 template <u32 THREADS>
 __device__ __forceinline__ void stream_trailing_nullmap(const Ctx& c, const ProgramHeader& hdr, u32 root_idx) {
-  if (root_idx + 1 < hdr.n_steps) write_nullmap<THREADS>(c, step_at(c, root_idx + 1));
+  if (root_idx + 1 >= hdr.n_steps) return;
+  __syncthreads();  // every wave is done with the ring
+  for (u32 s = root_idx + 1; s < hdr.n_steps; s++) {
+    const Step& st = step_at(c, s);
+    switch (uniform(st.kind)) {
+      case S_BITMAP_CLEAR: bitmap_clear<THREADS>(c, st); break;
+      case S_BITMAP_SET: bitmap_set<THREADS>(c, st); break;
+      case S_BITMAP_RANK: bitmap_rank<THREADS>(c, st); break;
+      case S_NULLMAP: write_nullmap<THREADS>(c, st); break;
+      default: break;
+    }
+    __syncthreads();
+  }
 }
 
 template <u32 THREADS, u32 BASE>

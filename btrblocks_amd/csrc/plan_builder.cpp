@@ -605,8 +605,13 @@ void build_program(const ColumnSource& src, BuiltProgram& out) {
   // LDS, and its group index is built while decoding instead of in a separate pass.
   {
     const Pipe& rp = bld.pipes[root];
-    // a byte-per-row nullmap that is one constant is written by the stream kernels themselves
-    const bool const_nullmap = !src.want_nullmap || src.nullmap_type == NM_ALLONES || src.nullmap_type == NM_ALLZEROS;
+    // a byte-per-row nullmap is written by the stream kernels themselves, behind the root step
+    // (a Roaring nullmap is expanded behind the root too, in the LDS the payload ring no longer
+    // needs: its bitmap and rank table must fit there)
+    const uint64_t nm_words = n / 64 + 1;
+    const bool const_nullmap = !src.want_nullmap || src.nullmap_type == NM_ALLONES || src.nullmap_type == NM_ALLZEROS ||
+                               ((src.nullmap_type == NM_REGULAR || src.nullmap_type == NM_FLIPPED) &&
+                                align_up(nm_words * 8, 16) + nm_words * 4 <= kStreamRingBytes);
     bool eligible = src.column_type == COL_INTEGER && rp.base == B_BP && rp.n_post <= 1 &&
                     const_nullmap && bld.bp_steps.size() == 1 && n > 0;
     for (const Step& st : bld.steps)
@@ -679,11 +684,17 @@ void build_program(const ColumnSource& src, BuiltProgram& out) {
       if (bld.pipes[bld.bp_steps[k].a[0]].a[5] > kWalkScratchMinGroups) bld.bp_steps[k].a[1] = scratch_slot(k % 4);
     if (!kernel_is_generic(kernel)) bld.steps.back().a[3] = scratch_slot(0);
   }
+  uint32_t ring_bits = NONE, ring_rank = NONE;
   if (src.want_nullmap) {
     if (src.nullmap_type == NM_REGULAR || src.nullmap_type == NM_FLIPPED) {
       const Builder::Bitmap bm = bld.add_bitmap(n);
       bld.roaring_steps(src.nullmap_off, bm, n, true);
       bld.add_step(S_NULLMAP, src.nullmap_type, bm.bits, NONE, n);
+      if (!kernel_is_generic(kernel)) {
+        ring_bits = bm.bits;  // placed in the payload ring, which is idle behind the root step
+        ring_rank = bm.rank;
+        bld.seqs[bm.bits].must_lds = bld.seqs[bm.rank].must_lds = 3;
+      }
     } else if (src.nullmap_type == NM_ALLONES || src.nullmap_type == NM_ALLZEROS) {
       bld.add_step(S_NULLMAP, src.nullmap_type, NONE, NONE, n);
     } else {
@@ -697,11 +708,16 @@ void build_program(const ColumnSource& src, BuiltProgram& out) {
   const size_t prog_bytes = sizeof(ProgramHeader) + n_steps * sizeof(Step) + bld.pipes.size() * sizeof(Pipe) +
                             bld.seqs.size() * sizeof(Seq) + bld.consts.size() * 4;
   const uint32_t table_base = prog_base + align_up((uint32_t)prog_bytes, 16) + 64;  // + reduction scratch
+  if (ring_bits != NONE) {
+    // offsets are relative to the table base: these two wrap around to LDS addresses 0.. (the ring)
+    bld.seqs[ring_bits].off = 0u - table_base;
+    bld.seqs[ring_rank].off = (uint32_t)align_up(bld.seqs[ring_bits].count * 8, 16) - table_base;
+  }
   uint64_t lds = 0, scratch = 0;
   auto place_tables = [&]() {
     lds = scratch = 0;
     for (auto& s : bld.seqs)
-      if (s.loc == LOC_LDS && s.must_lds) {
+      if (s.loc == LOC_LDS && s.must_lds && s.must_lds != 3) {
         s.off = (uint32_t)lds;
         lds += align_up(s.count * s.esize, 16);
       }
@@ -715,7 +731,7 @@ void build_program(const ColumnSource& src, BuiltProgram& out) {
       for (Step& st : bld.bp_steps) st.a[1] = NONE;
       lds = 0;
       for (auto& s : bld.seqs)
-        if (s.loc == LOC_LDS && s.must_lds) {
+        if (s.loc == LOC_LDS && s.must_lds && s.must_lds != 3) {
           s.off = (uint32_t)lds;
           lds += align_up(s.count * s.esize, 16);
         }
