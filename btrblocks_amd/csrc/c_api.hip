@@ -260,7 +260,9 @@ const char* btr_kernel_name(uint32_t k) {
   static const char* const names[KERNEL_KINDS] = {
       "btr_decode_int_kernel",      "btr_decode_dbl_kernel",      "btr_stream_none_kernel",  "btr_stream_add_kernel",
       "btr_stream_dict_lds_kernel", "btr_stream_dict_glb_kernel", "btr_stream_pseudo_kernel", "btr_stream_dictd_kernel",
-      "btr_decode_int_pfor_kernel", "btr_decode_dbl_pfor_kernel"};
+      "btr_decode_int_pfor_kernel", "btr_decode_dbl_pfor_kernel",
+      "btr_stream_none_nm_kernel", "btr_stream_add_nm_kernel", "btr_stream_dict_lds_nm_kernel",
+      "btr_stream_dict_glb_nm_kernel", "btr_stream_pseudo_nm_kernel", "btr_stream_dictd_nm_kernel"};
   return k < KERNEL_KINDS ? names[k] : nullptr;
 }
 
@@ -458,7 +460,10 @@ btr_status btr_gpu_ctx_create(int device, btr_gpu_ctx** out) {
                            (const void*)btr_stream_none_kernel,     (const void*)btr_stream_add_kernel,
                            (const void*)btr_stream_dict_lds_kernel, (const void*)btr_stream_dict_glb_kernel,
                            (const void*)btr_stream_pseudo_kernel,   (const void*)btr_stream_dictd_kernel,
-                           (const void*)btr_decode_int_pfor_kernel, (const void*)btr_decode_dbl_pfor_kernel};
+                           (const void*)btr_decode_int_pfor_kernel, (const void*)btr_decode_dbl_pfor_kernel,
+                           (const void*)btr_stream_none_nm_kernel,  (const void*)btr_stream_add_nm_kernel,
+                           (const void*)btr_stream_dict_lds_nm_kernel, (const void*)btr_stream_dict_glb_nm_kernel,
+                           (const void*)btr_stream_pseudo_nm_kernel, (const void*)btr_stream_dictd_nm_kernel};
   for (const void* k : kernels) {
     hipFuncAttributes attr;
     e = hipFuncGetAttributes(&attr, k);
@@ -636,7 +641,9 @@ btr_status btr_gpu_plan_stats(const btr_gpu_plan* plan, btr_plan_stats* out) {
 }
 
 static unsigned threads_of(uint32_t kind) {
-  return kind == KERNEL_STREAM_DICTD ? kDictdThreads : kernel_is_generic(kind) ? kBlockThreads : kStreamThreads;
+  return kind == KERNEL_STREAM_DICTD || kind == KERNEL_STREAM_DICTD + KERNEL_STREAM_NULLMAP ? kDictdThreads
+         : kernel_is_generic(kind)                                                         ? kBlockThreads
+                                                                                           : kStreamThreads;
 }
 using DecodeKernel = void (*)(const WorkItem*, const uint32_t*, const uint8_t*, uint32_t*);
 static DecodeKernel kernel_of(uint32_t kind) {
@@ -644,7 +651,10 @@ static DecodeKernel kernel_of(uint32_t kind) {
                                                      btr_stream_none_kernel,     btr_stream_add_kernel,
                                                      btr_stream_dict_lds_kernel, btr_stream_dict_glb_kernel,
                                                      btr_stream_pseudo_kernel,   btr_stream_dictd_kernel,
-                                                     btr_decode_int_pfor_kernel, btr_decode_dbl_pfor_kernel};
+                                                     btr_decode_int_pfor_kernel, btr_decode_dbl_pfor_kernel,
+                                                     btr_stream_none_nm_kernel,  btr_stream_add_nm_kernel,
+                                                     btr_stream_dict_lds_nm_kernel, btr_stream_dict_glb_nm_kernel,
+                                                     btr_stream_pseudo_nm_kernel, btr_stream_dictd_nm_kernel};
   return kernels[kind];
 }
 

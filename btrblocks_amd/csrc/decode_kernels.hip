@@ -2651,7 +2651,9 @@ __device__ __forceinline__ void bitmap_rank(const Ctx& c, const Step& s) {
 }
 
 // extern/RoaringBitmap.cpp:32-53: one byte per row, 1 = valid.
-template <u32 THREADS = kBlockThreads>
+// WIDE: 16 rows per lane for Roaring maps too (the stream kernels; the generic kernels keep the
+// short byte loop, whose registers every other program of theirs would pay for).
+template <u32 THREADS = kBlockThreads, bool WIDE = false>
 __device__ __forceinline__ void write_nullmap(const Ctx& c, const Step& s) {
   const u32 type = uniform(s.a[0]), n = uniform(s.a[3]);
   const u32 bits_off = uniform(s.a[1]) == NONE ? 0 : seq_lds(c, uniform(s.a[1]));
@@ -2671,7 +2673,7 @@ __device__ __forceinline__ void write_nullmap(const Ctx& c, const Step& s) {
   }
   const u32 flip = type == btrfmt::NM_REGULAR ? 0u : 0xFFFFu;
   u32 done = 0;
-  if ((reinterpret_cast<u64>(c.nullmap) & 15) == 0) {
+  if (WIDE && (reinterpret_cast<u64>(c.nullmap) & 15) == 0) {
     // sixteen rows per lane: four bits become four bytes by one multiply (bit k lands in byte k)
     const u32 body = n / 16;
     for (u32 q = threadIdx.x; q < body; q += THREADS) {
@@ -2709,7 +2711,7 @@ __device__ __forceinline__ void stream_trailing_nullmap(const Ctx& c, const Prog
       case S_BITMAP_CLEAR: bitmap_clear<THREADS>(c, st); break;
       case S_BITMAP_SET: bitmap_set<THREADS>(c, st); break;
       case S_BITMAP_RANK: bitmap_rank<THREADS>(c, st); break;
-      case S_NULLMAP: write_nullmap<THREADS>(c, st); break;
+      case S_NULLMAP: write_nullmap<THREADS, true>(c, st); break;
       default: break;
     }
     __syncthreads();
@@ -2770,14 +2772,14 @@ __device__ __forceinline__ void copy_to_lds(u32 lds_off, const u8* __restrict__ 
 
 // Lean kernel body for chunks whose program is [optional dictionary copy into LDS] + streamed
 // bit-packed root: DICT(BP), FOR(BP) and plain BP integer columns.
-template <u32 PS>
+template <u32 PS, bool NM>
 __device__ __forceinline__ void stream_block(const WorkItem* __restrict__ items, const u32* __restrict__ order,
                                              const u8* __restrict__ programs, u32* __restrict__ status) {
   const u32 item = order[blockIdx.x];
   const WorkItem it = items[item];
   Ctx c;
   const ProgramHeader hdr = load_program<kStreamThreads, kStreamProgBase>(it, item, programs, status, c);
-  const u32 root_idx = stream_root_index(c, hdr);
+  const u32 root_idx = NM ? stream_root_index(c, hdr) : hdr.n_steps - 1;
   for (u32 s = 0; s < root_idx; s++) {  // dictionary copies: a bare source sequence -> LDS
     const Step& st = step_at(c, s);
     const Tab from = resolve_tab(c, uniform(pipe_at(c, uniform(st.a[0])).a[0]));
@@ -2789,10 +2791,11 @@ __device__ __forceinline__ void stream_block(const WorkItem* __restrict__ items,
   const u32 pipe_id = uniform(root.a[0]);
   const IntEval e = resolve_int(c, pipe_id);
   stream_int_bp<PS>(c, pipe_at(c, pipe_id), e, reinterpret_cast<u32*>(c.dst), jump_scratch(c, root));
-  stream_trailing_nullmap<kStreamThreads>(c, hdr, root_idx);
+  if (NM) stream_trailing_nullmap<kStreamThreads>(c, hdr, root_idx);
 }
 
 // DICT(BP) double chunks: [dictionary copy into LDS] + streamed root.
+template <bool NM>
 __device__ __forceinline__ void stream_dictd_block(const WorkItem* __restrict__ items, const u32* __restrict__ order,
                                                    const u8* __restrict__ programs, u32* __restrict__ status) {
   const u32 item = order[blockIdx.x];
@@ -2800,7 +2803,7 @@ __device__ __forceinline__ void stream_dictd_block(const WorkItem* __restrict__ 
   Ctx c;
   stamp(it, 0);
   const ProgramHeader hdr = load_program<kDictdThreads, kStreamProgBase>(it, item, programs, status, c);
-  const u32 root_idx = stream_root_index(c, hdr);
+  const u32 root_idx = NM ? stream_root_index(c, hdr) : hdr.n_steps - 1;
   for (u32 s = 0; s < root_idx; s++) {
     const Step& st = step_at(c, s);
     const Tab from = resolve_tab(c, uniform(pipe_at(c, uniform(st.a[0])).a[0]));
@@ -2811,12 +2814,13 @@ __device__ __forceinline__ void stream_dictd_block(const WorkItem* __restrict__ 
   stamp(it, 1);
   const Step& root = step_at(c, root_idx);
   stream_dictd(c, pipe_at(c, uniform(root.a[0])), reinterpret_cast<u64*>(c.dst), jump_scratch(c, root));
-  stream_trailing_nullmap<kDictdThreads>(c, hdr, root_idx);
+  if (NM) stream_trailing_nullmap<kDictdThreads>(c, hdr, root_idx);
   stamp(it, 2);
 }
 
 // PSEUDODECIMAL(BP, BP, raw patches) chunks. The program is [clear bitmap, rank, streamed root]:
 // the exception bitmap is filled by a ring pass over the exponent stream between the first two.
+template <bool NM>
 __device__ __forceinline__ void stream_pseudo_block(const WorkItem* __restrict__ items, const u32* __restrict__ order,
                                                     const u8* __restrict__ programs, u32* __restrict__ status) {
   const u32 item = order[blockIdx.x];
@@ -2825,7 +2829,7 @@ __device__ __forceinline__ void stream_pseudo_block(const WorkItem* __restrict__
   stamp(it, 0);
   const ProgramHeader hdr = load_program<kStreamThreads, kStreamProgBase>(it, item, programs, status, c);
   stamp(it, 1);
-  const u32 root_idx = stream_root_index(c, hdr);
+  const u32 root_idx = NM ? stream_root_index(c, hdr) : hdr.n_steps - 1;
   const Step& root = step_at(c, root_idx);
   const Pipe& rp = pipe_at(c, uniform(root.a[0]));
   const Pipe& pd = pipe_at(c, uniform(rp.a[0]));
@@ -2862,7 +2866,7 @@ __device__ __forceinline__ void stream_pseudo_block(const WorkItem* __restrict__
   __syncthreads();
   stamp(it, 4);
   stream_pseudo(c, rp, pd, pe, rk, reinterpret_cast<u64*>(c.dst), frac_off, jump_off, xc);
-  stream_trailing_nullmap<kStreamThreads>(c, hdr, root_idx);
+  if (NM) stream_trailing_nullmap<kStreamThreads>(c, hdr, root_idx);
   stamp(it, 5);
 }
 
@@ -2927,34 +2931,34 @@ btr_decode_dbl_kernel(const WorkItem* __restrict__ items, const u32* __restrict_
 extern "C" __global__ void __launch_bounds__(kStreamThreads)
 btr_stream_none_kernel(const WorkItem* __restrict__ items, const u32* __restrict__ order,
                        const u8* __restrict__ programs, u32* __restrict__ status) {
-  stream_block<PS_NONE>(items, order, programs, status);
+  stream_block<PS_NONE, false>(items, order, programs, status);
 }
 extern "C" __global__ void __launch_bounds__(kStreamThreads)
 btr_stream_add_kernel(const WorkItem* __restrict__ items, const u32* __restrict__ order,
                       const u8* __restrict__ programs, u32* __restrict__ status) {
-  stream_block<PS_ADD>(items, order, programs, status);
+  stream_block<PS_ADD, false>(items, order, programs, status);
 }
 extern "C" __global__ void __launch_bounds__(kStreamThreads)
 btr_stream_dict_lds_kernel(const WorkItem* __restrict__ items, const u32* __restrict__ order,
                            const u8* __restrict__ programs, u32* __restrict__ status) {
-  stream_block<PS_DICT_LDS>(items, order, programs, status);
+  stream_block<PS_DICT_LDS, false>(items, order, programs, status);
 }
 extern "C" __global__ void __launch_bounds__(kStreamThreads)
 btr_stream_dict_glb_kernel(const WorkItem* __restrict__ items, const u32* __restrict__ order,
                            const u8* __restrict__ programs, u32* __restrict__ status) {
-  stream_block<PS_DICT_GLB>(items, order, programs, status);
+  stream_block<PS_DICT_GLB, false>(items, order, programs, status);
 }
 // PSEUDODECIMAL(BP, BP, raw patches) double columns (plan.h: KERNEL_STREAM_PSEUDO).
 extern "C" __global__ void __launch_bounds__(kStreamThreads) __attribute__((amdgpu_waves_per_eu(8, 8)))
 btr_stream_pseudo_kernel(const WorkItem* __restrict__ items, const u32* __restrict__ order,
                          const u8* __restrict__ programs, u32* __restrict__ status) {
-  stream_pseudo_block(items, order, programs, status);
+  stream_pseudo_block<false>(items, order, programs, status);
 }
 // DICT(BP) double columns (plan.h: KERNEL_STREAM_DICTD).
-extern "C" __global__ void __launch_bounds__(kDictdThreads)
+extern "C" __global__ void __launch_bounds__(kDictdThreads) __attribute__((amdgpu_waves_per_eu(8, 8)))
 btr_stream_dictd_kernel(const WorkItem* __restrict__ items, const u32* __restrict__ order,
                         const u8* __restrict__ programs, u32* __restrict__ status) {
-  stream_dictd_block(items, order, programs, status);
+  stream_dictd_block<false>(items, order, programs, status);
 }
 
 // The generic kernels with the PFOR step (plan.h: KERNEL_PFOR_INT / KERNEL_PFOR_DBL).
@@ -2969,3 +2973,18 @@ btr_decode_dbl_pfor_kernel(const WorkItem* __restrict__ items, const u32* __rest
                            const u8* __restrict__ programs, u32* __restrict__ status) {
   decode_block<true, true>(items, order, programs, status);
 }
+
+// The stream kernels with the nullmap steps behind the root (plan.h: stream kind + KERNEL_STREAM_NULLMAP).
+#define BTR_STREAM_NULLMAP_KERNEL(name, threads, body)                                                     \
+  extern "C" __global__ void __launch_bounds__(threads) __attribute__((amdgpu_waves_per_eu(8, 8)))         \
+  name(const WorkItem* __restrict__ items, const u32* __restrict__ order, const u8* __restrict__ programs, \
+       u32* __restrict__ status) {                                                                          \
+    body(items, order, programs, status);                                                                   \
+  }
+BTR_STREAM_NULLMAP_KERNEL(btr_stream_none_nm_kernel, kStreamThreads, (stream_block<PS_NONE, true>))
+BTR_STREAM_NULLMAP_KERNEL(btr_stream_add_nm_kernel, kStreamThreads, (stream_block<PS_ADD, true>))
+BTR_STREAM_NULLMAP_KERNEL(btr_stream_dict_lds_nm_kernel, kStreamThreads, (stream_block<PS_DICT_LDS, true>))
+BTR_STREAM_NULLMAP_KERNEL(btr_stream_dict_glb_nm_kernel, kStreamThreads, (stream_block<PS_DICT_GLB, true>))
+BTR_STREAM_NULLMAP_KERNEL(btr_stream_pseudo_nm_kernel, kStreamThreads, (stream_pseudo_block<true>))
+BTR_STREAM_NULLMAP_KERNEL(btr_stream_dictd_nm_kernel, kDictdThreads, (stream_dictd_block<true>))
+#undef BTR_STREAM_NULLMAP_KERNEL

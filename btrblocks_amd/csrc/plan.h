@@ -157,9 +157,14 @@ enum : uint32_t {
   KERNEL_STREAM_DICTD = 7,     // DICT(BP) doubles, dictionary staged in LDS or read from the compressed bytes
   KERNEL_PFOR_INT = 8,         // the generic kernels again, with the S_PFOR_DECODE step compiled in (the
   KERNEL_PFOR_DBL = 9,         // plain ones leave it out: it costs every other program registers)
-  KERNEL_KINDS = 10,
+  // 10..15: the stream kernels 2..7 with the nullmap steps behind the root compiled in (kept apart
+  // for the same reason: registers)
+  KERNEL_STREAM_NULLMAP = 8,   // added to a stream kind
+  KERNEL_KINDS = 16,
 };
-constexpr bool kernel_is_generic(uint32_t k) { return k <= KERNEL_GENERIC_DBL || k >= KERNEL_PFOR_INT; }
+constexpr bool kernel_is_generic(uint32_t k) {
+  return k <= KERNEL_GENERIC_DBL || k == KERNEL_PFOR_INT || k == KERNEL_PFOR_DBL;
+}
 
 constexpr uint32_t kBlockThreads = 256;
 constexpr uint32_t kStreamRingBytes = 16 * 1024;  // LDS ring of the streamed root step (4 batches of 1024 words)

@@ -923,7 +923,7 @@ void build_program(const ColumnSource& src, BuiltProgram& out) {
   memcpy(p, bld.seqs.data(), bld.seqs.size() * sizeof(Seq));
   p += bld.seqs.size() * sizeof(Seq);
   if (!bld.consts.empty()) memcpy(p, bld.consts.data(), bld.consts.size() * 4);
-  out.kernel = kernel;
+  out.kernel = !kernel_is_generic(kernel) && src.want_nullmap ? kernel + KERNEL_STREAM_NULLMAP : kernel;
   out.lds_bytes = table_base + (uint32_t)lds;
   out.scratch_bytes = (uint32_t)scratch;
   out.needed_bytes = bld.needed;
