@@ -1970,7 +1970,12 @@ __device__ __forceinline__ void mat_pseudo_rle4(const Ctx& c, const DblEval& e, 
     put(fa, ia, oa);
     put(fb, ib, ob);
   }
-  if (tid < count - quads) dst[quads + tid] = eval_dbl<B_PSEUDO, B_RLE, B_RLE, PS_NONE>(e, quads + tid, bad);
+  {
+    // the last count % 4 rows; every lane evaluates (the powers of ten are fetched by lane permute,
+    // which reads from active lanes only), the first few store
+    const u64 v = eval_dbl<B_PSEUDO, B_RLE, B_RLE, PS_NONE>(e, quads + tid < count ? quads + tid : count - 1, bad);
+    if (tid < count - quads) dst[quads + tid] = v;
+  }
   report(c, bad);
 }
 
