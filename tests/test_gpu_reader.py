@@ -132,6 +132,8 @@ def test_cpp_interface_round_trip(spec):
     ("rle(bp,bp)", "int_rle"), ("dict(bp)", "int_dict"), ("pfor", "int_outliers"), ("rle(pfor,pfor)", "int_rle"),
     ("frequency(bp)", "int_frequency"), ("pseudodecimal(bp,bp,uncompressed)", "double_decimal"),
     ("dict(bp)", "double_dict"), ("rle(uncompressed,bp)", "double_runs"),
+    ("pseudodecimal", "double_decimal"), ("for(bp)", "int_for"),
+    ("pseudodecimal(rle(bp,bp),rle(bp,bp),uncompressed)", "double_decimal_runs"),
 ])
 def test_corrupted_payloads_never_fault(gpu_ctx, spec, gen):
     """Random damage anywhere behind the chunk header: the decode either completes (with whatever
@@ -154,6 +156,33 @@ def test_corrupted_payloads_never_fault(gpu_ctx, spec, gen):
     # the undamaged chunk still decodes bit-exactly afterwards
     out = gpu_ctx.decode_chunk_host(chunk)
     assert np.array_equal(np.asarray(out).view(np.uint8), values.view(np.uint8))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("spec,gen", [
+    ("dict(bp)", "int_dict"), ("for(bp)", "int_for"), ("pseudodecimal", "double_decimal"), ("dict(bp)", "double_dict"),
+    ("rle(bp,bp)", "int_rle"),
+])
+def test_corrupted_payloads_with_nullmap_never_fault(gpu_ctx, spec, gen):
+    """The same with a Roaring nullmap in the chunk and the byte-per-row map requested (the damage
+    may hit the serialized bitmap as well)."""
+    values = getattr(synth, gen)(65536)
+    nullmap = synth.random_nullmap(65536, 0.8, seed=21)
+    chunk = B.compress_chunk(values, nullmap, spec)
+    import zlib
+    rng = np.random.default_rng(zlib.crc32((spec + gen + "nm").encode()))
+    for trial in range(6):
+        bad = chunk.copy()
+        for _ in range(int(rng.integers(1, 4))):
+            lo = 12 + int(rng.integers(0, bad.size - 12 - 8))
+            bad[lo:lo + 8] = rng.integers(0, 256, 8).astype(np.uint8)
+        try:
+            out, nm = gpu_ctx.decode_chunk_host(bad, want_nullmap=True)
+            assert out.shape == (65536,) and nm.shape == (65536,)
+        except B.BtrError as e:
+            assert e.status in (2, 3, 6), e
+    out, nm = gpu_ctx.decode_chunk_host(chunk, want_nullmap=True)
+    assert np.array_equal(nm.astype(bool), nullmap.astype(bool))
 
 
 @pytest.mark.gpu
