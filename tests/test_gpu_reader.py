@@ -52,6 +52,36 @@ def test_reader_with_nullmaps(gpu_ctx):
     np.testing.assert_array_equal(r.getBitmap(0), nm[:65536])
 
 
+@pytest.mark.parametrize("double", [False, True])
+@pytest.mark.parametrize("nulls", [None, 0.9])
+def test_reader_column_of_mixed_chunks(gpu_ctx, double, nulls):
+    """Every block of the column has another character, so the compressor picks another cascade per
+    block and one decode call launches several kernel kinds side by side."""
+    n = 65536
+    if double:
+        parts = [synth.double_decimal(n), synth.double_dict(n), synth.double_runs(n), synth.double_decimal_runs(n),
+                 np.full(n, 2.5), np.random.default_rng(5).random(n), synth.double_dict(20000)]
+    else:
+        parts = [synth.int_rle(n), synth.int_dict(n), synth.int_for(n), synth.int_outliers(n),
+                 np.full(n, 7, np.int32), synth.int_frequency(n), synth.int_dict(20000)]
+    values = np.concatenate(parts)
+    nm = None if nulls is None else synth.random_nullmap(values.size, nulls, seed=9)
+    image = B.compress_column(values, nm, "auto", threads=4)
+    r = B.BtrReader(image, ctx=gpu_ctx)
+    assert r.getChunkCount() == len(parts)
+    r.decodeAll(with_nullmap=nm is not None)
+    got = r.column_host()
+    for i, (o, c) in enumerate(r.chunks):
+        want = pyoracle.decode_chunk(image[o:o + c])
+        np.testing.assert_array_equal(_bits(got[i * n:i * n + want.size]), _bits(want))
+    if nm is None:
+        np.testing.assert_array_equal(_bits(got), _bits(values))
+    else:
+        np.testing.assert_array_equal(r.d_nullmap[:values.size].cpu().numpy(), nm)
+        valid = nm.astype(bool)
+        np.testing.assert_array_equal(_bits(got[valid]), _bits(values[valid]))
+
+
 def test_datablock_decompress(gpu_ctx):
     n = 640000  # tools/examples/compression.cpp compresses the whole relation as one block
     cols = [(synth.example_runs(n, seed=42), None, "auto"),
