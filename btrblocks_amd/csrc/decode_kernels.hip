@@ -2911,7 +2911,7 @@ __device__ __forceinline__ void decode_block(const WorkItem* __restrict__ items,
         break;
       default: break;
     }
-    __syncthreads();
+    if (!uniform(st.no_barrier)) __syncthreads();
     stamp(it, 3 + s - hdr.n_bp_steps);
   }
 }

@@ -101,7 +101,8 @@ enum : uint8_t {
 enum : uint32_t { SET_ARRAY32 = 0, SET_ARRAY16 = 1, SET_BITSET = 2, SET_RUNS = 3 };
 struct Step {
   uint8_t kind;
-  uint8_t pad[3];
+  uint8_t no_barrier;  // the next step depends on nothing this one writes: the workgroup runs on into it
+  uint8_t pad[2];
   uint32_t a[6];
 };
 
