@@ -2967,7 +2967,7 @@ btr_stream_dictd_kernel(const WorkItem* __restrict__ items, const u32* __restric
 }
 
 // The generic kernels with the PFOR step (plan.h: KERNEL_PFOR_INT / KERNEL_PFOR_DBL).
-extern "C" __global__ void __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(6, 8)))
+extern "C" __global__ void __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(5, 8)))
 btr_decode_int_pfor_kernel(const WorkItem* __restrict__ items, const u32* __restrict__ order,
                            const u8* __restrict__ programs, u32* __restrict__ status) {
   decode_block<false, true>(items, order, programs, status);
