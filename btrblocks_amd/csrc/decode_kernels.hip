@@ -2228,35 +2228,26 @@ __device__ __forceinline__ void vbyte_tail_decode(const Ctx& c, __amdgpu_buffer_
 }
 
 // Wait of a wave that streams packed words into its LDS ring and stores unpacked values in
-// between: everything but the newest `blocks` * 4 store instructions and (if `newer_load`) one
-// load behind them has completed. The wait count is an immediate, so one case per block count;
-// counts beyond the counter's range wait for a little more than needed.
-__device__ __forceinline__ void pfor_wait(u32 blocks, bool newer_load) {
-#define BTR_PFOR_WAIT_CASE(k)                                       \
-  case k:                                                           \
-    if (newer_load)                                                 \
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * k + 1) : "memory"); \
-    else                                                            \
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * k) : "memory");  \
-    break;
-  switch (blocks < 15 ? blocks : 15) {
-    BTR_PFOR_WAIT_CASE(0)
-    BTR_PFOR_WAIT_CASE(1)
-    BTR_PFOR_WAIT_CASE(2)
-    BTR_PFOR_WAIT_CASE(3)
-    BTR_PFOR_WAIT_CASE(4)
-    BTR_PFOR_WAIT_CASE(5)
-    BTR_PFOR_WAIT_CASE(6)
-    BTR_PFOR_WAIT_CASE(7)
-    BTR_PFOR_WAIT_CASE(8)
-    BTR_PFOR_WAIT_CASE(9)
-    BTR_PFOR_WAIT_CASE(10)
-    BTR_PFOR_WAIT_CASE(11)
-    BTR_PFOR_WAIT_CASE(12)
-    BTR_PFOR_WAIT_CASE(13)
-    BTR_PFOR_WAIT_CASE(14)
-    BTR_PFOR_WAIT_CASE(15)
+// between: everything but the newest `newer` vector memory instructions (loads and stores
+// complete in issue order on one counter) has completed. The wait count is an immediate, so one
+// case per count; counts beyond the counter's range wait for a little more than needed.
+__device__ __forceinline__ void pfor_wait(u32 newer) {
+#define BTR_PFOR_WAIT_CASE(k) \
+  case k: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(k) : "memory"); break;
+#define BTR_PFOR_WAIT_CASE8(k)                                                                          \
+  BTR_PFOR_WAIT_CASE(k) BTR_PFOR_WAIT_CASE(k + 1) BTR_PFOR_WAIT_CASE(k + 2) BTR_PFOR_WAIT_CASE(k + 3) \
+  BTR_PFOR_WAIT_CASE(k + 4) BTR_PFOR_WAIT_CASE(k + 5) BTR_PFOR_WAIT_CASE(k + 6) BTR_PFOR_WAIT_CASE(k + 7)
+  switch (newer < 63 ? newer : 63) {
+    BTR_PFOR_WAIT_CASE8(0)
+    BTR_PFOR_WAIT_CASE8(8)
+    BTR_PFOR_WAIT_CASE8(16)
+    BTR_PFOR_WAIT_CASE8(24)
+    BTR_PFOR_WAIT_CASE8(32)
+    BTR_PFOR_WAIT_CASE8(40)
+    BTR_PFOR_WAIT_CASE8(48)
+    BTR_PFOR_WAIT_CASE8(56)
   }
+#undef BTR_PFOR_WAIT_CASE8
 #undef BTR_PFOR_WAIT_CASE
 }
 
@@ -2410,7 +2401,7 @@ __device__ __forceinline__ void pfor_decode(const Ctx& c, const Step& s) {
     BTR_STAMP(c, 10);
     // 3. every wave takes a contiguous quarter of the blocks, whose packed words are contiguous
     //    too, and streams them through its own 4 KiB LDS ring in 1 KiB pieces (one direct-to-LDS
-    //    load each, two pieces ahead): iteration p unpacks the blocks that start in piece p (they
+    //    load each, three pieces ahead): iteration p unpacks the blocks that start in piece p (they
     //    may run into piece p+1, which has landed); lane l extracts values l, l+64, l+128, l+192.
     {
       const u32 lane = tid & 63, wave = uniform(tid >> 6);
@@ -2430,40 +2421,55 @@ __device__ __forceinline__ void pfor_decode(const Ctx& c, const Step& s) {
         };
         issue(0);
         issue(1);
+        issue(2);
         u32 r = r_begin;
         const bool to_global = out.loc != LOC_LDS;
         const __amdgpu_buffer_rsrc_t out_rsrc = make_rsrc(to_global ? out.g : nullptr, to_global ? out.count * 4 : 0);
-        u32 stored = 0;  // blocks stored (four store instructions each) since the last wait
+        const bool wide = to_global && (reinterpret_cast<u64>(out.g) & 15) == 0;  // 16-byte stores
+        u32 stored = 0, stored_before = 0;  // store instructions of the previous iteration and of the one before
         for (u32 piece = 0; piece < pieces && r < r_end; piece++) {
-          const bool more = piece + 2 < pieces;
-          issue(piece + 2);  // its slot held piece - 2
-          // Pieces <= piece + 1 must have landed. Loads and stores complete in issue order on one
-          // counter: behind the load of piece + 1 this wave issued the stores of the previous
-          // iteration and (if any) the load above, and exactly those may stay in flight.
-          pfor_wait(to_global ? stored : 0u, more);
+          // The slot of piece - 1: a block is at most one piece long, so the blocks that started in
+          // it ended inside this one, and their values have been stored.
+          issue(piece + 3);
+          // Pieces <= piece + 1 must have landed. Behind the load of piece + 1 this wave issued the
+          // stores of the last two iterations and the loads of the next two pieces (if any), and
+          // exactly those may stay in flight.
+          pfor_wait(stored + stored_before + (piece + 2 < pieces) + (piece + 3 < pieces));
+          stored_before = stored;
           stored = 0;
           while (r < r_end) {
             const u32 rel = uniform(lds32(table_off + 16 * r + 12)) - w_lo;
             if (rel >= kPiece * (piece + 1)) break;
             const u32 b = uniform(lds32(table_off + 16 * r)) & 0xFF;
             const u32 mask = b >= 32 ? ~0u : (1u << b) - 1u;
-            u32 v[4];
-#pragma unroll
-            for (u32 q = 0; q < 4; q++) {
-              const u32 bit = ((lane >> 2) + 16 * (q & 1)) * b;
-              const u32 w = rel + (q >> 1) * 4 * b + 4 * (bit >> 5) + (lane & 3);
-              const u32 x = __builtin_amdgcn_alignbit(lds32(ring + 4 * ((w + 4) & (kRing - 1))),
-                                                      lds32(ring + 4 * (w & (kRing - 1))), bit);
-              v[q] = x & mask;
-            }
-            const u32 o = (first + r * btrfmt::PFOR_BLOCK + lane) * 4;
+            // lane l takes values 4l..4l+3 of the block: they sit at the same bit of four adjacent
+            // words (one per 32-bit lane of the SIMD pack), so two 16-byte LDS reads fetch all of them
+            const u32 bit = (lane & 31) * b;
+            const u32 w = rel + (lane >> 5) * 4 * b + 4 * (bit >> 5);
+            const u32x4 lo = *reinterpret_cast<const u32x4*>(lds_raw + ring + 4 * (w & (kRing - 1)));
+            const u32x4 hi = *reinterpret_cast<const u32x4*>(lds_raw + ring + 4 * ((w + 4) & (kRing - 1)));
+            u32x4 v;
+            v.x = __builtin_amdgcn_alignbit(hi.x, lo.x, bit) & mask;
+            v.y = __builtin_amdgcn_alignbit(hi.y, lo.y, bit) & mask;
+            v.z = __builtin_amdgcn_alignbit(hi.z, lo.z, bit) & mask;
+            v.w = __builtin_amdgcn_alignbit(hi.w, lo.w, bit) & mask;
+            const u32 o = (first + r * btrfmt::PFOR_BLOCK + 4 * lane) * 4;
             if (to_global) {
-#pragma unroll
-              for (u32 q = 0; q < 4; q++) __builtin_amdgcn_raw_buffer_store_b32(v[q], out_rsrc, o + 256 * q, 0, 0);
-              stored++;
+              if (wide) {
+                __builtin_amdgcn_raw_buffer_store_b128(v, out_rsrc, o, 0, 0);
+                stored++;
+              } else {
+                __builtin_amdgcn_raw_buffer_store_b32(v.x, out_rsrc, o, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(v.y, out_rsrc, o + 4, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(v.z, out_rsrc, o + 8, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(v.w, out_rsrc, o + 12, 0, 0);
+                stored += 4;
+              }
             } else {
-#pragma unroll
-              for (u32 q = 0; q < 4; q++) lds_st32(out.lds + o + 256 * q, v[q]);
+              lds_st32(out.lds + o, v.x);
+              lds_st32(out.lds + o + 4, v.y);
+              lds_st32(out.lds + o + 8, v.z);
+              lds_st32(out.lds + o + 12, v.w);
             }
             r++;
           }
@@ -2475,7 +2481,67 @@ __device__ __forceinline__ void pfor_decode(const Ctx& c, const Step& s) {
     // 4. exceptions, one thread each: exception e of the page belongs to the block r with
     //    ebase[r] <= e < ebase[r + 1]; (value >> b) << b is ORed back in at its position
     constexpr u32 kPatchUnroll = 4;  // exceptions per thread whose loads are in flight together
-    for (u32 e0 = 0; e0 < total_exc; e0 += kBlockThreads * kPatchUnroll) {
+    // Into global memory: no branch between a thread's loads, so the packed exception values and
+    // the low bits of all its exceptions are in flight together. Dead lanes, exceptions without
+    // stored bits (width 1) and out-of-range indexes read and write past their buffer
+    // descriptors (loads return 0, stores are dropped).
+    const bool patch_global = out.loc != LOC_LDS;
+    const __amdgpu_buffer_rsrc_t patch_rsrc = make_rsrc(patch_global ? out.g : nullptr, patch_global ? out.count * 4 : 0);
+    constexpr u32 kNowhere = 0xFFFFFFF0u;
+    for (u32 e0 = 0; patch_global && e0 < total_exc; e0 += kBlockThreads * kPatchUnroll) {
+      u32 at[kPatchUnroll], lo_at[kPatchUnroll], hi_at[kPatchUnroll], sh[kPatchUnroll], width[kPatchUnroll];
+#pragma unroll
+      for (u32 u = 0; u < kPatchUnroll; u++) {
+        const u32 en_raw = e0 + u * kBlockThreads + tid;
+        bool live = en_raw < total_exc;
+        const u32 en = live ? en_raw : 0u;
+        u32 r = 0;  // the last block whose first exception is at or before en
+#pragma unroll
+        for (u32 step = 128; step; step >>= 1) {
+          const u32 cand = r + step;
+          if (cand < blocks && lds32(ebase_off + 4 * (cand < blocks ? cand : 0u)) <= en) r = cand;
+        }
+        const u32 x = en - lds32(ebase_off + 4 * r);
+        const u32 e = lds32(table_off + 16 * r), pos_off = lds32(table_off + 16 * r + 4), ex0 = lds32(table_off + 16 * r + 8);
+        const u32 b = e & 0xFF, k = e >> 16;
+        live = live && b < 32;
+        const u32 kc = k >= 2 ? k : 2u;
+        const u32 cls_word = lds32(d + 4 * (5 + kc - 2));
+        const u32 cls_size = k >= 2 ? lds32(d + 4 * (5 + 31 + kc - 2)) : 0u;
+        const u32 full = cls_size & ~127u;
+        const u32 pos = staged && pos_off + x < bytes_off + bytes_size
+                            ? (u32)lds_raw[bytes_lds + skew + (pos_off - bytes_off) + x]
+                            : __builtin_amdgcn_raw_buffer_load_b8(rsrc, pos_off + x, 0, 0);  // past the payload: 0
+        const u32 q = ex0 + x;
+        if (live && k >= 2 && q >= cls_size) bad = 1;
+        const bool stored_bits = live && k >= 2 && q < cls_size;
+        const bool simd = q < full;  // whole SIMD packs of 128 first, then plain packs of 32
+        const u32 qq = q - full;
+        const u32 bit = (simd ? (q & 127) >> 2 : qq & 31) * k;
+        const u32 w = simd ? cls_word + (q >> 7) * 4 * k + 4 * (bit >> 5) + (q & 3)
+                           : cls_word + (full >> 7) * 4 * k + (qq >> 5) * k + (bit >> 5);
+        lo_at[u] = stored_bits ? w * 4 : kNowhere;
+        hi_at[u] = stored_bits ? (w + (simd ? 4u : 1u)) * 4 : kNowhere;
+        sh[u] = (bit & 31) | (b << 8) | ((live && k < 2 ? 1u : 0u) << 16);
+        width[u] = stored_bits ? k : 0u;
+        at[u] = live ? (first + r * btrfmt::PFOR_BLOCK + pos) * 4 : kNowhere;
+      }
+      u32 lo[kPatchUnroll], hi[kPatchUnroll], old[kPatchUnroll];
+#pragma unroll
+      for (u32 u = 0; u < kPatchUnroll; u++) {
+        lo[u] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, lo_at[u], 0, 0);
+        hi[u] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, hi_at[u], 0, 0);
+        old[u] = __builtin_amdgcn_raw_buffer_load_b32(patch_rsrc, at[u], 0, 0);
+      }
+#pragma unroll
+      for (u32 u = 0; u < kPatchUnroll; u++) {
+        const u32 x = __builtin_amdgcn_alignbit(hi[u], lo[u], sh[u] & 31);
+        const u32 k = width[u];
+        const u32 v = (k >= 32 ? x : x & ((1u << k) - 1u)) | (sh[u] >> 16);  // width 1: the bit is a one
+        __builtin_amdgcn_raw_buffer_store_b32(old[u] | (v << ((sh[u] >> 8) & 31)), patch_rsrc, at[u], 0, 0);
+      }
+    }
+    for (u32 e0 = 0; !patch_global && e0 < total_exc; e0 += kBlockThreads * kPatchUnroll) {
       u32 at[kPatchUnroll], hi_bits[kPatchUnroll], old[kPatchUnroll];
       bool live[kPatchUnroll];
 #pragma unroll
