@@ -1,5 +1,7 @@
 """Seeded random sweep: sizes, trees and nullmap densities that the hand-written case list does not
 enumerate, GPU against the oracle at every row, with and without the byte-per-row nullmap."""
+import os
+
 import numpy as np
 import pytest
 
@@ -41,7 +43,11 @@ def _dbl_values(rng, n, kind):
     return v
 
 
-@pytest.mark.parametrize("seed", range(300))
+# BTR_SWEEP_FIRST / BTR_SWEEP_CASES: other and larger seed ranges for one-off runs
+_FIRST = int(os.environ.get("BTR_SWEEP_FIRST", "0"))
+
+
+@pytest.mark.parametrize("seed", range(_FIRST, _FIRST + int(os.environ.get("BTR_SWEEP_CASES", "300"))))
 def test_random_chunk(gpu_ctx, seed):
     rng = np.random.default_rng(9000 + seed)
     n = int(rng.choice([1, 17, 127, 128, 129, 1000, 4097, 16960, 40000, 65535, 65536]))
