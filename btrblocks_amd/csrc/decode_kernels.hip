@@ -2403,11 +2403,16 @@ __device__ __forceinline__ void pfor_decode(const Ctx& c, const Step& s) {
     //    too, and streams them through its own 4 KiB LDS ring in 1 KiB pieces (one direct-to-LDS
     //    load each, three pieces ahead): iteration p unpacks the blocks that start in piece p (they
     //    may run into piece p+1, which has landed); lane l extracts values l, l+64, l+128, l+192.
+    //    Unpack and patches alternate over sub-ranges of the page's blocks: a 4-byte patch that
+    //    arrives after its line has left the L2 costs a read-modify-write in memory.
+    constexpr u32 kSubBlocks = 64;
+    for (u32 sb = 0; sb < blocks; sb += kSubBlocks) {
+    const u32 se = sb + kSubBlocks < blocks ? sb + kSubBlocks : blocks;
     {
       const u32 lane = tid & 63, wave = uniform(tid >> 6);
       constexpr u32 kWaves = kBlockThreads / 64, kPiece = 256, kRing = 4 * kPiece;
       const u32 ring = packed_lds + 4 * kRing * wave;
-      const u32 r_begin = blocks * wave / kWaves, r_end = blocks * (wave + 1) / kWaves;
+      const u32 r_begin = sb + (se - sb) * wave / kWaves, r_end = sb + (se - sb) * (wave + 1) / kWaves;
       if (r_begin < r_end) {
         const u32 w_lo = uniform(lds32(table_off + 16 * r_begin + 12));
         const u32 last_e = uniform(lds32(table_off + 16 * (r_end - 1)));
@@ -2478,6 +2483,7 @@ __device__ __forceinline__ void pfor_decode(const Ctx& c, const Step& s) {
     }
     __syncthreads();  // also orders the stores above before the patches below
     BTR_STAMP(c, 11);
+    const u32 e_first = uniform(lds32(ebase_off + 4 * sb)), e_last = se < blocks ? uniform(lds32(ebase_off + 4 * se)) : total_exc;
     // 4. exceptions, one thread each: exception e of the page belongs to the block r with
     //    ebase[r] <= e < ebase[r + 1]; (value >> b) << b is ORed back in at its position
     constexpr u32 kPatchUnroll = 4;  // exceptions per thread whose loads are in flight together
@@ -2488,12 +2494,12 @@ __device__ __forceinline__ void pfor_decode(const Ctx& c, const Step& s) {
     const bool patch_global = out.loc != LOC_LDS;
     const __amdgpu_buffer_rsrc_t patch_rsrc = make_rsrc(patch_global ? out.g : nullptr, patch_global ? out.count * 4 : 0);
     constexpr u32 kNowhere = 0xFFFFFFF0u;
-    for (u32 e0 = 0; patch_global && e0 < total_exc; e0 += kBlockThreads * kPatchUnroll) {
+    for (u32 e0 = e_first; patch_global && e0 < e_last; e0 += kBlockThreads * kPatchUnroll) {
       u32 at[kPatchUnroll], lo_at[kPatchUnroll], hi_at[kPatchUnroll], sh[kPatchUnroll], width[kPatchUnroll];
 #pragma unroll
       for (u32 u = 0; u < kPatchUnroll; u++) {
         const u32 en_raw = e0 + u * kBlockThreads + tid;
-        bool live = en_raw < total_exc;
+        bool live = en_raw < e_last;
         const u32 en = live ? en_raw : 0u;
         u32 r = 0;  // the last block whose first exception is at or before en
 #pragma unroll
@@ -2541,13 +2547,13 @@ __device__ __forceinline__ void pfor_decode(const Ctx& c, const Step& s) {
         __builtin_amdgcn_raw_buffer_store_b32(old[u] | (v << ((sh[u] >> 8) & 31)), patch_rsrc, at[u], 0, 0);
       }
     }
-    for (u32 e0 = 0; !patch_global && e0 < total_exc; e0 += kBlockThreads * kPatchUnroll) {
+    for (u32 e0 = e_first; !patch_global && e0 < e_last; e0 += kBlockThreads * kPatchUnroll) {
       u32 at[kPatchUnroll], hi_bits[kPatchUnroll], old[kPatchUnroll];
       bool live[kPatchUnroll];
 #pragma unroll
       for (u32 u = 0; u < kPatchUnroll; u++) {
         const u32 en = e0 + u * kBlockThreads + tid;
-        live[u] = en < total_exc;
+        live[u] = en < e_last;
         at[u] = hi_bits[u] = old[u] = 0;
         if (!live[u]) continue;
         u32 r = 0, hi = blocks;
@@ -2593,6 +2599,7 @@ __device__ __forceinline__ void pfor_decode(const Ctx& c, const Step& s) {
         if (live[u]) tab_st32(out, at[u], old[u] | hi_bits[u]);
     }
     __syncthreads();
+    }
   }
   if (bad) raise(c, ST_BP_HEADER);
   const u32 rounded = n / btrfmt::PFOR_BLOCK * btrfmt::PFOR_BLOCK;
