@@ -3,11 +3,20 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-Workload (N=1): three synthetic int32 columns of `--rows` values each (default 268 435 456 = 1 GiB
-raw, 4096 blocks of 65 536 rows), one forcing RLE(BP,BP), one DICT(BP), one FOR(BP). One step =
-one decode pass over all three columns with the compressed chunks already resident in HBM.
-With N>1 every rank decodes its own three columns (different seeds) on its own GPU: block ranges
-shard with no data-path collective, so scaling is weak and `value` is the sum over ranks.
+N = 1 (default): four synthetic columns of `--rows` values each (default 268 435 456 = 4096 blocks
+of 65 536 rows): int32 RLE(BP,BP), DICT(BP), FOR(BP) (1 GiB raw each) and a decimal-like double
+column forcing PSEUDODECIMAL(BP,BP,UNCOMPRESSED) (2 GiB raw). One step = one decode pass over all
+columns with the compressed chunks already resident in HBM.
+
+N > 1: ONE mixed relation of 8 int32 + 4 double columns x `--rows` rows (16 GiB raw; nested
+cascades of depth 3) whose blocks are sharded over the ranks as contiguous block ranges balanced
+by decoded bytes (btrblocks_amd.shard.shard_ranges); every rank generates, compresses, uploads and
+decodes only its own range; no data-path collective. The relation does not depend on N (it is
+generated in segments of 512 blocks with fixed seeds), so scaling is strong and `value` is the
+whole relation's decoded bytes over the slowest rank's time.
+Launch: `python bench.py --gpus N` spawns the N ranks itself (one process per GPU) when it was
+not started by torch.distributed.run; under torch.distributed.run it reads RANK / LOCAL_RANK /
+WORLD_SIZE from the environment.
 
 Prints ONE JSON line: metric/value (GB/s of uncompressed output, whole job), `roofline`
 (algorithmic bytes = compressed bytes the decoder needs + decoded bytes written, per launch,
@@ -17,6 +26,8 @@ decompression-speed harness on a bounded sample of the same chunks, rank 0 at N=
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -26,6 +37,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
+BLOCK_ROWS = 65536
+SEGMENT_BLOCKS = 512   # the sharded relation is generated in segments of this many blocks
 
 COLUMNS = {
     # name: (generator, scheme spec, column seed)
@@ -46,69 +59,163 @@ COLUMNS = {
     "onevalue": ("int_constant", "onevalue", 5),
     "uncompressed": ("int_for", "uncompressed", 6),
 }
+SINGLE_GPU_COLUMNS = "rle,dict,for,pseudodecimal"
+RELATION_COLUMNS = "rle,dict,for,rle_dict,for_rle,freq_dict,pfor,onevalue,pseudodecimal,pseudo_rle,dbl_dict,dbl_rle"
 
 
-def build_columns(names, rows, rank, threads, valid_fraction=None):
+def column_elem_bytes(name):
+    return 8 if COLUMNS[name][0].startswith("double") else 4
+
+
+def rank_block_range(names, rows, rank, world):
+    """Block range of this rank: contiguous, balanced by the decoded bytes of all columns."""
+    from btrblocks_amd import shard
+    blocks = (rows + BLOCK_ROWS - 1) // BLOCK_ROWS
+    block_rows = np.full(blocks, BLOCK_ROWS, dtype=np.int64)
+    block_rows[-1] = rows - (blocks - 1) * BLOCK_ROWS
+    per_row = sum(column_elem_bytes(n) for n in names)
+    return shard.shard_ranges(block_rows * per_row, world)[rank]
+
+
+def generate_range(name, rows, b0, b1, segmented):
+    """Rows of blocks [b0, b1) of column `name`. Segmented: the column is the concatenation of
+    segments of SEGMENT_BLOCKS blocks, segment s generated with seed + 1000 * s, so any rank can
+    produce its range without the rest of the column."""
+    from btrblocks_amd import synth
+    gen, _, seed = COLUMNS[name]
+    fn = getattr(synth, gen)
+    r0, r1 = b0 * BLOCK_ROWS, min(rows, b1 * BLOCK_ROWS)
+    if not segmented:
+        return fn(rows, seed=seed)[r0:r1]
+    seg_rows = SEGMENT_BLOCKS * BLOCK_ROWS
+    parts = []
+    for s in range(r0 // seg_rows, (r1 + seg_rows - 1) // seg_rows):
+        s0 = s * seg_rows
+        n = min(seg_rows, rows - s0)
+        v = fn(n, seed=seed + 1000 * s)
+        parts.append(v[max(r0, s0) - s0:min(r1, s0 + n) - s0])
+    return np.ascontiguousarray(np.concatenate(parts)) if len(parts) != 1 else np.ascontiguousarray(parts[0])
+
+
+def build_columns(names, rows, b0, b1, segmented, threads, valid_fraction=None):
     import btrblocks_amd as B
     from btrblocks_amd import synth
     cols = []
     for name in names:
-        gen, spec, seed = COLUMNS[name]
+        _, spec, seed = COLUMNS[name]
         t0 = time.time()
-        values = getattr(synth, gen)(rows, seed=seed + 1000 * rank)
+        values = generate_range(name, rows, b0, b1, segmented)
         t1 = time.time()
-        nullmap = None if valid_fraction is None else synth.random_nullmap(rows, valid_fraction, seed=seed + 77)
+        nullmap = None if valid_fraction is None else synth.random_nullmap(values.size, valid_fraction, seed=seed + 77 + b0)
         image = B.compress_column(values, nullmap, spec, threads=threads)
         t2 = time.time()
-        cols.append({"name": name, "spec": spec, "image": image, "raw_bytes": values.nbytes,
+        cols.append({"name": name, "spec": spec, "image": image, "raw_bytes": values.nbytes, "rows": values.size,
                      "gen_s": t1 - t0, "compress_s": t2 - t1})
         del values
     return cols
 
 
 def cpu_baseline(cols, sample_chunks, budget_s=12.0):
-    """Restated decompression-speed (oracle) over the first `sample_chunks` chunks of each column."""
+    """Restated decompression-speed (oracle) over the first `sample_chunks` chunks of each column:
+    all host threads (the reference's TBB pool) and one thread, in GB/s (1e9) and in the
+    reference's own unit (decompressed MiB per second, decompression-speed.cpp:205-238)."""
     import btrblocks_amd as B
     from oracle import pyoracle
     total_s, total_bytes, threads = 0.0, 0, 0
+    one_s, one_bytes = 0.0, 0
     per = {}
     for c in cols:
         chunks = B.part_chunks(c["image"])[:sample_chunks]
         sec, nbytes, threads = pyoracle.decompression_speed(c["image"], chunks, threads=0, reps=1)
-        reps = int(max(1, min(40, (budget_s / len(cols)) / max(sec, 1e-6))))
+        reps = int(max(1, min(40, (0.7 * budget_s / len(cols)) / max(sec, 1e-6))))
         sec, nbytes, threads = pyoracle.decompression_speed(c["image"], chunks, threads=0, reps=reps)
         per[c["name"]] = round(nbytes / sec / 1e9, 3)
         total_s += sec
         total_bytes += nbytes
+        few = chunks[:max(1, sample_chunks // 8)]
+        sec1, nbytes1, _ = pyoracle.decompression_speed(c["image"], few, threads=1, reps=1)
+        reps1 = int(max(1, min(10, (0.3 * budget_s / len(cols)) / max(sec1, 1e-6))))
+        sec1, nbytes1, _ = pyoracle.decompression_speed(c["image"], few, threads=1, reps=reps1)
+        one_s += sec1
+        one_bytes += nbytes1
     return {
         "value": round(total_bytes / total_s / 1e9, 3),
         "unit": "GB/s",
         "cores": threads,
         "kind": "port",
         "sample": f"first {sample_chunks} chunks (65536 rows each) of every column, CPU oracle restating "
-                  f"decompression-speed (one task per chunk, {threads} std::threads, warm-up + timed passes)",
+                  f"decompression-speed (one task per chunk, {threads} std::threads, warm-up + timed passes); "
+                  f"one-thread figure on the first {max(1, sample_chunks // 8)} chunks",
+        "MiB_per_s": round(total_bytes / total_s / 2**20, 1),
+        "one_thread": {"value": round(one_bytes / one_s / 1e9, 3), "unit": "GB/s", "cores": 1,
+                       "MiB_per_s": round(one_bytes / one_s / 2**20, 1)},
         "per_column": per,
     }
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--rows", type=int, default=268435456, help="rows per column")
-    ap.add_argument("--columns", default="rle,dict,for")
+    ap.add_argument("--rows", type=int, default=268435456,
+                    help="rows per column (N = 1) / rows of the sharded relation (N > 1)")
+    ap.add_argument("--columns", default=None,
+                    help=f"default: {SINGLE_GPU_COLUMNS} at N = 1, the mixed relation ({RELATION_COLUMNS}) at N > 1")
+    ap.add_argument("--relation", action="store_true", help="N = 1: decode the mixed relation of the N > 1 runs")
     ap.add_argument("--cpu-sample-chunks", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--nulls", type=float, default=None, metavar="P",
                     help="give every column a random nullmap with a fraction P of valid rows and decode the byte-per-row maps too")
-    ap.add_argument("--verify", action="store_true", help="compare a sample of chunks with the oracle")
-    ap.add_argument("--verify-stride", type=int, default=257, help="with --verify: check every N-th chunk")
+    ap.add_argument("--no-verify", action="store_true", help="skip the oracle check of a sample of blocks after the timed region")
+    ap.add_argument("--verify-stride", type=int, default=257, help="check every N-th chunk (and the last one)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
     ap.add_argument("--one-device", action="store_true",
                     help="rehearsal on a one-GPU box: every rank uses cuda:0 (needs --backend gloo)")
-    args = ap.parse_args()
+    return ap.parse_args()
 
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` outside torch.distributed.run: this process never touches the GPU,
+    starts one child per rank, forwards rank 0's JSON line and fails if any rank fails."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    if bad:
+        print(f"bench.py: ranks failed (rank, exit code): {bad}", file=sys.stderr)
+        return 1
+    return 0
+
+
+def verify_sample(reader, stride):
+    """Every stride-th chunk and the last one against the CPU oracle, bit for bit."""
+    from oracle import pyoracle
+    n = len(reader.chunks)
+    checked = 0
+    for i in sorted(set(list(range(0, n, stride)) + [n - 1])):
+        o, ln = reader.chunks[i]
+        want = pyoracle.decode_chunk(reader.image[o:o + ln])
+        lo = int(reader.out_offsets[i])
+        got = reader.d_out[lo:lo + want.nbytes].cpu().numpy()
+        if not np.array_equal(got, want.view(np.uint8)):
+            raise AssertionError(f"chunk {i} differs from the oracle")
+        checked += 1
+    return checked
+
+
+def run_rank(args):
     import torch
     import torch.distributed as dist
 
@@ -125,27 +232,31 @@ def main():
             dist.init_process_group(args.backend)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    red_dev = dev if args.backend == "nccl" else torch.device("cpu")  # where the two scalar reductions live
+    red_dev = dev if args.backend == "nccl" else torch.device("cpu")  # where the scalar reductions live
 
     import btrblocks_amd as B
     from btrblocks_amd import api
 
-    names = [n.strip() for n in args.columns.split(",") if n.strip()]
+    relation = world > 1 or args.relation
+    names = [n.strip() for n in (args.columns or (RELATION_COLUMNS if relation else SINGLE_GPU_COLUMNS)).split(",") if n.strip()]
+    b0, b1 = rank_block_range(names, args.rows, rank, world)
     host_threads = max(1, (os.cpu_count() or 8) // max(1, world))
-    host_threads = min(host_threads, int(os.environ.get("OMP_NUM_THREADS", host_threads)) if world == 1 else host_threads)
-    cols = build_columns(names, args.rows, rank, host_threads, args.nulls)
+    host_threads = min(host_threads, int(os.environ.get("OMP_NUM_THREADS", host_threads)))
+    cols = build_columns(names, args.rows, b0, b1, relation, host_threads, args.nulls)
     want_nm = args.nulls is not None
 
     ctx = B.GpuContext(local_rank)
     readers = []
-    t_plan = 0.0
+    t_open = 0.0
     for c in cols:
         t0 = time.time()
-        r = B.BtrReader(c["image"], ctx=ctx)
-        r.plan(None, want_nm)
-        t_plan += time.time() - t0
+        r = B.BtrReader(c["image"], ctx=ctx)  # envelopes in one call + upload of the image
+        t_open += time.time() - t0
         readers.append(r)
+    torch.cuda.synchronize()
+    t0 = time.time()
     plans = [r.plan(None, want_nm) for r in readers]
+    t_plan = time.time() - t0
     stats = [p.stats for p in plans]
     out_bytes = sum(s.decoded_bytes for s in stats)
     alg_bytes = sum(s.decoded_bytes + s.needed_bytes for s in stats)
@@ -170,17 +281,6 @@ def main():
     barrier()
     for p in plans:  # malformed-stream flags of the warm-up passes
         p.check(stream)
-    if args.verify:
-        from oracle import pyoracle
-        for r in readers:
-            host = r.column_host()
-            pos = 0
-            for i, (o, n) in enumerate(r.chunks):
-                rows = r.infos[i].tuple_count
-                if i % args.verify_stride == 0:
-                    want = pyoracle.decode_chunk(r.image[o:o + n])
-                    assert np.array_equal(host[pos:pos + rows].view(np.uint8), want.view(np.uint8)), f"chunk {i} differs"
-                pos += rows
 
     evs = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in plans]
            for _ in range(args.steps)]
@@ -193,16 +293,25 @@ def main():
     elapsed = t1 - t0
     for p in plans:
         p.check(stream)
+    verified = 0
+    if not args.no_verify:
+        verified = sum(verify_sample(r, args.verify_stride) for r in readers)
 
+    my_ms = elapsed / args.steps * 1e3
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        tot = torch.tensor([float(out_bytes)], dtype=torch.float64, device=red_dev)
+        tot = torch.tensor([float(out_bytes), float(verified)], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-        total_out = float(tot.item())
+        total_out, verified_all = float(tot[0].item()), int(tot[1].item())
+        per_rank = [torch.zeros(3, dtype=torch.float64, device=red_dev) for _ in range(world)]
+        dist.all_gather(per_rank, torch.tensor([my_ms, float(b0), float(b1)], dtype=torch.float64, device=red_dev))
+        per_rank = [{"rank": r, "ms_per_step": round(float(v[0]), 4), "blocks": [int(v[1]), int(v[2])]}
+                    for r, v in enumerate(per_rank)]
     else:
-        total_out = float(out_bytes)
+        total_out, verified_all = float(out_bytes), verified
+        per_rank = [{"rank": 0, "ms_per_step": round(my_ms, 4), "blocks": [b0, b1]}]
 
     # per-launch kernel durations from HIP events on the launch stream
     kern_ms = np.array([[a.elapsed_time(b) for (a, b) in evs[k]] for k in range(args.steps)])  # steps x columns
@@ -221,7 +330,7 @@ def main():
             "needed_bytes": int(s.needed_bytes),
             "stored_bytes": int(s.stored_bytes),
             "decoded_bytes": int(s.decoded_bytes),
-            "alg_bytes_per_value": round(ab / s.tuples, 3),
+            "alg_bytes_per_value": round(ab / max(1, s.tuples), 3),
             "lds_bytes": int(s.max_lds_bytes),
         }
     # kernel behind each plan (one launch per plan in this workload)
@@ -242,12 +351,13 @@ def main():
     if rank == 0:
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath):
-            try:
+        if os.path.exists(tpath) and world == 1 and args.rows == 268435456:
+            try:  # HBM bytes per launch from the PMC passes of the same columns (profiles/collect.sh)
                 traffic = json.load(open(tpath)).get("bytes_per_launch", {}).get(
                     per_column[cols[dom]["name"]]["kernels"][0])
             except Exception:
                 traffic = None
+        dtypes = sorted({"f64" if column_elem_bytes(n) == 8 else "int32" for n in names})
         line = {
             "metric": "device-resident decompression GB/s (uncompressed output)",
             "value": round(total_out * args.steps / elapsed / 1e9, 2),
@@ -257,17 +367,22 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if world > 1 else "weak",
             "vs_baseline": None,
-            "dtype": "int32" if all(c["raw_bytes"] == 4 * args.rows for c in cols) else "int32+f64",
+            "dtype": "+".join(dtypes),
             "data": "synthetic",
             "config": {
-                "workload": f"{len(names)} synthetic columns x {args.rows} rows ({','.join(c['spec'] for c in cols)}), "
-                            f"65536-row blocks, compressed chunks resident in HBM, one workgroup per block",
-                "rows_per_column": args.rows,
-                "blocks_per_column": int(stats[0].chunks),
-                "per_gpu_output_bytes": int(out_bytes),
+                "workload": (f"mixed relation of {len(names)} columns x {args.rows} rows "
+                             f"({','.join(c['spec'] for c in cols)}), blocks sharded over {world} GPU(s) as contiguous ranges"
+                             if relation else
+                             f"{len(names)} synthetic columns x {args.rows} rows ({','.join(c['spec'] for c in cols)})")
+                            + ", 65536-row blocks, compressed chunks resident in HBM, one workgroup per block",
+                "rows": args.rows,
+                "blocks": int((args.rows + BLOCK_ROWS - 1) // BLOCK_ROWS),
+                "total_output_bytes": int(total_out),
+                "rank0_output_bytes": int(out_bytes),
                 "sharding": "independent block ranges per GPU, no collective",
+                "verified_chunks": verified_all,
             },
             "roofline": {
                 "bound": "hbm",
@@ -285,10 +400,16 @@ def main():
                                  "alg_bytes_per_step": int(alg_bytes), "kernel_ms_per_step": round(float(mean_ms.sum()), 4)},
                 "per_column": per_column,
             },
+            "per_rank": per_rank,
             "host": {
-                "plan_build_s": round(t_plan, 3),
+                "open_s": round(t_open, 3),          # part inspection + H2D upload of the compressed images
+                "plan_s": round(t_plan, 3),          # btr_gpu_plan_create_part, all columns
+                "plan_compile_s": round(sum(s.compile_seconds for s in stats), 4),
+                "plan_upload_s": round(sum(s.upload_seconds for s in stats), 4),
+                "chunks": int(sum(s.chunks for s in stats)),
                 "compress_s": round(sum(c["compress_s"] for c in cols), 2),
                 "generate_s": round(sum(c["gen_s"] for c in cols), 2),
+                "threads": host_threads,
             },
         }
         if world == 1 and not args.no_cpu_baseline:
@@ -297,6 +418,13 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
+    run_rank(args)
 
 
 if __name__ == "__main__":

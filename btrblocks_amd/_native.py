@@ -83,6 +83,8 @@ class PlanStats(C.Structure):
         ("max_depth", C.c_uint32),
         ("kernel_mask", C.c_uint32),
         ("launches", C.c_uint32),
+        ("compile_seconds", C.c_double),
+        ("upload_seconds", C.c_double),
     ]
 
 
@@ -95,6 +97,8 @@ SIGNATURES = {
     "btr_chunk_describe": (C.c_int, [_P, C.c_size_t, C.c_char_p, C.c_size_t]),
     "btr_part_chunk_count": (C.c_int, [_P, C.c_size_t, C.POINTER(C.c_uint32)]),
     "btr_part_chunk": (C.c_int, [_P, C.c_size_t, C.c_uint32, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    "btr_part_inspect": (C.c_int, [_P, C.c_size_t, C.c_uint32, C.c_uint32, C.POINTER(ChunkInfo), C.POINTER(C.c_uint64),
+                                   C.POINTER(C.c_uint64)]),
     "btr_datablock_inspect": (C.c_int, [_P, C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "btr_datablock_column": (C.c_int, [_P, C.c_size_t, C.c_uint32, C.POINTER(ChunkInfo)]),
     "btr_compress_bound": (C.c_size_t, [C.c_uint8, C.c_uint32]),
@@ -109,6 +113,8 @@ SIGNATURES = {
     "btr_gpu_ctx_create": (C.c_int, [C.c_int, C.POINTER(_P)]),
     "btr_gpu_ctx_destroy": (None, [_P]),
     "btr_gpu_plan_create": (C.c_int, [_P, C.POINTER(ChunkDesc), C.c_size_t, C.POINTER(_P)]),
+    "btr_gpu_plan_create_part": (C.c_int, [_P, _P, _P, C.c_size_t, C.c_uint32, C.c_uint32, _P, C.c_size_t, _P,
+                                           C.c_size_t, C.POINTER(_P)]),
     "btr_gpu_plan_create_datablock": (C.c_int, [_P, _P, _P, C.c_size_t, C.POINTER(_P), C.POINTER(_P),
                                                 C.c_uint32, C.POINTER(_P)]),
     "btr_gpu_plan_destroy": (None, [_P]),

@@ -63,18 +63,26 @@ def describe(chunk):
     return out.value.decode()
 
 
-def part_chunks(part):
-    """[(offset, length)] of the chunks of a column part image."""
+def part_inspect(part):
+    """Envelopes of every chunk of a column part image in one call: (infos, offsets, lengths) with
+    infos a ctypes array of ChunkInfo and offsets / lengths uint64 numpy arrays."""
     lib = N.load()
     a = _as_u8(part)
     n = C.c_uint32()
     N.check(lib.btr_part_chunk_count(a.ctypes.data, a.size, C.byref(n)))
-    out = []
-    off, ln = C.c_size_t(), C.c_size_t()
-    for i in range(n.value):
-        N.check(lib.btr_part_chunk(a.ctypes.data, a.size, i, C.byref(off), C.byref(ln)))
-        out.append((off.value, ln.value))
-    return out
+    infos = (N.ChunkInfo * n.value)()
+    offsets = np.zeros(n.value, dtype=np.uint64)
+    lengths = np.zeros(n.value, dtype=np.uint64)
+    N.check(lib.btr_part_inspect(a.ctypes.data, a.size, 0, n.value, infos,
+                                 offsets.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                 lengths.ctypes.data_as(C.POINTER(C.c_uint64))))
+    return infos, offsets, lengths
+
+
+def part_chunks(part):
+    """[(offset, length)] of the chunks of a column part image."""
+    _, offsets, lengths = part_inspect(part)
+    return list(zip(offsets.tolist(), lengths.tolist()))
 
 
 def datablock_columns(block):
@@ -200,6 +208,20 @@ class DecodePlan:
         h = C.c_void_p()
         N.check(self.lib.btr_gpu_plan_create(ctx.handle, arr, len(descs), C.byref(h)))
         self.handle = h
+
+    @classmethod
+    def for_part(cls, ctx, host_part, dev_ptr, first, count, dst_ptr, dst_bytes, nullmap_ptr=None, nullmap_bytes=0,
+                 keepalive=()):
+        """Plan over chunks [first, first + count) of a part image resident at dev_ptr
+        (btr_gpu_plan_create_part: one call, outputs back to back)."""
+        self = cls.__new__(cls)
+        self.ctx, self.lib, self._keep = ctx, ctx.lib, keepalive
+        a = _as_u8(host_part)
+        h = C.c_void_p()
+        N.check(self.lib.btr_gpu_plan_create_part(ctx.handle, a.ctypes.data, dev_ptr, a.size, first, count, dst_ptr,
+                                                  dst_bytes, nullmap_ptr, nullmap_bytes, C.byref(h)))
+        self.handle = h
+        return self
 
     @classmethod
     def for_datablock(cls, ctx, host_block, dev_ptr, dsts, nullmap_dsts=None, keepalive=()):

@@ -5,7 +5,9 @@
 #include <algorithm>
 #include <atomic>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -146,34 +148,172 @@ struct btr_gpu_plan {
 
 namespace {
 
-// Uploads the built programs and work items of a plan.
-btr_status finish_plan(btr_gpu_ctx* ctx, std::vector<WorkItem>& items, std::vector<BuiltProgram>& progs,
-                       const std::vector<uint8_t>& is_double, btr_plan_stats stats, btr_gpu_plan** out) {
-  DeviceGuard guard(ctx->device);
-  if (!guard.ok) return fail(BTR_ERR_DEVICE, "hipSetDevice failed");
-  auto plan = new btr_gpu_plan();
-  plan->device = ctx->device;
-  plan->n_items = items.size();
-  std::vector<uint8_t> blob;
-  uint64_t scratch = 0;
+double now_s() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// Header walk and validation of every chunk; chunks are independent, so large plans are compiled
+// on several host threads (the first failing chunk is the one reported). Nothing thrown inside
+// escapes: a hostile header that exhausts memory is reported like any other malformed one.
+btr_status compile_chunks(const btr_chunk_desc* chunks, size_t n, std::vector<WorkItem>& items,
+                          std::vector<BuiltProgram>& progs, btr_plan_stats& stats) {
+  items.assign(n, WorkItem{});
+  progs.assign(n, BuiltProgram{});
+  std::vector<btr_chunk_info> infos(n);
+  auto compile = [&](size_t i, std::string& err) -> btr_status {
+    const btr_chunk_desc& d = chunks[i];
+    if (!d.host_src || !d.dev_src || !d.dev_dst) {
+      err = "null pointer";
+      return BTR_ERR_INVALID_ARGUMENT;
+    }
+    btr_chunk_info& info = infos[i];
+    btr_status st = parse_chunk((const uint8_t*)d.host_src, d.src_bytes, &info);
+    if (st != BTR_OK) {
+      err = g_error;
+      return st;
+    }
+    if (d.dst_bytes < info.decoded_bytes) {
+      err = "destination too small";
+      return BTR_ERR_BUFFER_TOO_SMALL;
+    }
+    if ((uint64_t)(uintptr_t)d.dev_dst % 8 != 0) {
+      err = "destination must be 8-byte aligned";
+      return BTR_ERR_MISALIGNED;
+    }
+    if (d.src_bytes > 0xFFFFFFFFull) {
+      err = "chunk above 4 GiB";
+      return BTR_ERR_UNSUPPORTED;
+    }
+    try {
+      build_program(chunk_source((const uint8_t*)d.host_src, d.src_bytes, (uint64_t)(uintptr_t)d.dev_src, info,
+                                 d.dev_nullmap_dst != nullptr),
+                    progs[i]);
+    } catch (const PlanError& e) {
+      err = e.what();
+      return (btr_status)e.status;
+    } catch (const std::bad_alloc&) {
+      err = "out of host memory while compiling the decode program";
+      return BTR_ERR_OUT_OF_MEMORY;
+    } catch (const std::exception& e) {
+      err = e.what();
+      return BTR_ERR_CORRUPT;
+    } catch (...) {
+      err = "unknown failure while compiling the decode program";
+      return BTR_ERR_CORRUPT;
+    }
+    WorkItem& it = items[i];
+    it.src = (uint64_t)(uintptr_t)d.dev_src;
+    it.dst = (uint64_t)(uintptr_t)d.dev_dst;
+    it.nullmap_dst = (uint64_t)(uintptr_t)d.dev_nullmap_dst;
+    it.tuple_count = info.tuple_count;
+    it.src_bytes = (uint32_t)d.src_bytes;
+    return BTR_OK;
+  };
+  const size_t hw = std::max(1u, std::thread::hardware_concurrency());
+  const size_t workers = n < 256 ? 1 : std::min<size_t>({hw, 16, n / 128});
+  std::vector<size_t> bad_at(workers, n);
+  std::vector<btr_status> bad_status(workers, BTR_OK);
+  std::vector<std::string> bad_text(workers);
+  auto run = [&](size_t w) {
+    const size_t lo = n * w / workers, hi = n * (w + 1) / workers;
+    for (size_t i = lo; i < hi; i++) {
+      const btr_status st = compile(i, bad_text[w]);
+      if (st != BTR_OK) {
+        bad_at[w] = i;
+        bad_status[w] = st;
+        return;
+      }
+    }
+  };
+  if (workers == 1) {
+    run(0);
+  } else {
+    std::vector<std::thread> pool;
+    for (size_t w = 0; w < workers; w++) pool.emplace_back(run, w);
+    for (auto& t : pool) t.join();
+  }
+  for (size_t w = 0; w < workers; w++)  // ranges are in chunk order: the first failure is the lowest index
+    if (bad_status[w] != BTR_OK) return fail(bad_status[w], "chunk " + std::to_string(bad_at[w]) + ": " + bad_text[w]);
+  for (size_t i = 0; i < n; i++) {
+    stats.tuples += infos[i].tuple_count;
+    stats.decoded_bytes += infos[i].decoded_bytes;
+    stats.stored_bytes += chunks[i].src_bytes;
+    stats.needed_bytes += CHUNK_DATA;
+    if (chunks[i].dev_nullmap_dst) stats.nullmap_bytes += infos[i].tuple_count;
+  }
+  return BTR_OK;
+}
+
+uint32_t debug_flags_from_env() {
   const char* dbg = getenv("BTR_DEBUG_FLAGS");  // kernel timing diagnostics, see plan.h
-  const uint32_t debug_flags = dbg ? (uint32_t)atoi(dbg) : 0;
+  uint32_t flags = dbg ? (uint32_t)atoi(dbg) : 0;
+#ifndef BTR_DEBUG_STEPS
+  flags &= 8;  // step skipping exists in diagnostic builds only
+#endif
+  return flags;
+}
+
+// Program blob, launch order and per-kind launch geometry of a set of compiled chunks.
+struct Layout {
+  std::vector<uint8_t> blob;
+  std::vector<uint32_t> order;
+  size_t kind_begin[KERNEL_KINDS + 1] = {};
+  uint32_t kind_lds[KERNEL_KINDS] = {};
+  uint64_t scratch = 0;
+};
+void lay_out(std::vector<WorkItem>& items, const std::vector<BuiltProgram>& progs, btr_plan_stats& stats, Layout& lo) {
+  size_t total = 0;
+  for (const BuiltProgram& p : progs) total += (p.program.size() + 15) / 16 * 16;
+  lo.blob.assign(total, 0);
+  size_t at = 0;
   for (size_t i = 0; i < items.size(); i++) {
-    items[i].debug_flags = debug_flags;
     items[i].pad = 0;
-    while (blob.size() % 16) blob.push_back(0);
-    items[i].prog_off = (uint32_t)blob.size();
+    items[i].prog_off = (uint32_t)at;
     items[i].prog_bytes = (uint32_t)progs[i].program.size();
-    blob.insert(blob.end(), progs[i].program.begin(), progs[i].program.end());
-    items[i].scratch = scratch;  // offset for now; rebased below
-    scratch += (progs[i].scratch_bytes + 255) / 256 * 256;
+    memcpy(lo.blob.data() + at, progs[i].program.data(), progs[i].program.size());
+    at += (progs[i].program.size() + 15) / 16 * 16;
+    items[i].scratch = lo.scratch;  // offset for now; rebased by the caller
+    lo.scratch += ((uint64_t)progs[i].scratch_bytes + 255) / 256 * 256;
     stats.max_lds_bytes = std::max(stats.max_lds_bytes, progs[i].lds_bytes);
     stats.max_depth = std::max(stats.max_depth, progs[i].depth);
     stats.needed_bytes += progs[i].needed_bytes;
   }
-  stats.scratch_bytes = scratch;
+  stats.scratch_bytes = lo.scratch;
   stats.chunks = items.size();
-  plan->stats = stats;
+  lo.order.reserve(items.size());
+  for (uint32_t kind = 0; kind < KERNEL_KINDS; kind++) {
+    lo.kind_begin[kind] = lo.order.size();
+    for (size_t i = 0; i < items.size(); i++)
+      if (progs[i].kernel == kind) {
+        lo.order.push_back((uint32_t)i);
+        lo.kind_lds[kind] = std::max(lo.kind_lds[kind], progs[i].lds_bytes);
+      }
+  }
+  lo.kind_begin[KERNEL_KINDS] = lo.order.size();
+  for (uint32_t kind = 0; kind < KERNEL_KINDS; kind++)
+    if (lo.kind_begin[kind + 1] > lo.kind_begin[kind]) {
+      stats.kernel_mask |= 1u << kind;
+      stats.launches++;
+    }
+}
+
+// Uploads the built programs and work items of a plan.
+btr_status finish_plan(btr_gpu_ctx* ctx, std::vector<WorkItem>& items, std::vector<BuiltProgram>& progs,
+                       btr_plan_stats stats, btr_gpu_plan** out) {
+  DeviceGuard guard(ctx->device);
+  if (!guard.ok) return fail(BTR_ERR_DEVICE, "hipSetDevice failed");
+  const double t_start = now_s();
+  auto plan = new btr_gpu_plan();
+  plan->device = ctx->device;
+  plan->n_items = items.size();
+  Layout lo;
+  lay_out(items, progs, stats, lo);
+  const uint32_t debug_flags = debug_flags_from_env();
+  for (WorkItem& it : items) it.debug_flags = debug_flags;
+  memcpy(plan->kind_begin, lo.kind_begin, sizeof(lo.kind_begin));
+  memcpy(plan->kind_lds, lo.kind_lds, sizeof(lo.kind_lds));
+  const std::vector<uint8_t>& blob = lo.blob;
+  const uint64_t scratch = lo.scratch;
   auto cleanup = [&](btr_status st) {
     btr_gpu_plan_destroy(plan);
     return st;
@@ -206,28 +346,13 @@ btr_status finish_plan(btr_gpu_ctx* ctx, std::vector<WorkItem>& items, std::vect
       return cleanup(hip_fail(e, "hipMemcpy(programs)"));
     if ((e = hipMemset(plan->d_status, 0, items.size() * 4)) != hipSuccess)
       return cleanup(hip_fail(e, "hipMemset(status)"));
-    std::vector<uint32_t> order;
-    for (uint32_t kind = 0; kind < KERNEL_KINDS; kind++) {
-      plan->kind_begin[kind] = order.size();
-      for (size_t i = 0; i < items.size(); i++)
-        if (progs[i].kernel == kind) {
-          order.push_back((uint32_t)i);
-          plan->kind_lds[kind] = std::max(plan->kind_lds[kind], progs[i].lds_bytes);
-        }
-    }
-    plan->kind_begin[KERNEL_KINDS] = order.size();
-    for (uint32_t kind = 0; kind < KERNEL_KINDS; kind++)
-      if (plan->kind_begin[kind + 1] > plan->kind_begin[kind]) {
-        plan->stats.kernel_mask |= 1u << kind;
-        plan->stats.launches++;
-      }
     size_t most = 0;
     for (uint32_t kind = 0; kind < KERNEL_KINDS; kind++)
       if (plan->kind_begin[kind + 1] - plan->kind_begin[kind] > most) {
         most = plan->kind_begin[kind + 1] - plan->kind_begin[kind];
         plan->main_kind = kind;
       }
-    if (plan->stats.launches > 1) {
+    if (stats.launches > 1) {
       if ((e = hipEventCreateWithFlags(&plan->fork, hipEventDisableTiming)) != hipSuccess)
         return cleanup(hip_fail(e, "hipEventCreate"));
       for (uint32_t kind = 0; kind < KERNEL_KINDS; kind++) {
@@ -241,12 +366,63 @@ btr_status finish_plan(btr_gpu_ctx* ctx, std::vector<WorkItem>& items, std::vect
           return cleanup(hip_fail(e, "hipEventCreate"));
       }
     }
-    if ((e = hipMalloc((void**)&plan->d_order, order.size() * 4)) != hipSuccess)
+    if ((e = hipMalloc((void**)&plan->d_order, lo.order.size() * 4)) != hipSuccess)
       return cleanup(hip_fail(e, "hipMalloc(order)"));
-    if ((e = hipMemcpy(plan->d_order, order.data(), order.size() * 4, hipMemcpyHostToDevice)) != hipSuccess)
+    if ((e = hipMemcpy(plan->d_order, lo.order.data(), lo.order.size() * 4, hipMemcpyHostToDevice)) != hipSuccess)
       return cleanup(hip_fail(e, "hipMemcpy(order)"));
   }
+  stats.upload_seconds = now_s() - t_start;
+  plan->stats = stats;
   *out = plan;
+  return BTR_OK;
+}
+
+btr_status create_plan(btr_gpu_ctx* ctx, const btr_chunk_desc* chunks, size_t n, btr_gpu_plan** out) {
+  std::vector<WorkItem> items;
+  std::vector<BuiltProgram> progs;
+  btr_plan_stats stats{};
+  const double t0 = now_s();
+  btr_status st;
+  try {
+    st = compile_chunks(chunks, n, items, progs, stats);
+  } catch (const std::bad_alloc&) {
+    return fail(BTR_ERR_OUT_OF_MEMORY, "out of host memory while compiling the plan");
+  }
+  if (st != BTR_OK) return st;
+  stats.compile_seconds = now_s() - t0;
+  return finish_plan(ctx, items, progs, stats, out);
+}
+
+// Chunk descriptors of chunks [first, first + count) of a column part image: outputs back to back
+// from dev_dst (every chunk start 16-byte aligned), nullmaps back to back by rows.
+btr_status part_descs(const void* host_part, const void* dev_part, size_t bytes, uint32_t first, uint32_t count,
+                      void* dev_dst, size_t dst_bytes, uint8_t* dev_nullmap_dst, size_t nullmap_bytes,
+                      std::vector<btr_chunk_desc>& descs) {
+  uint32_t total;
+  btr_status st = btr_part_chunk_count(host_part, bytes, &total);
+  if (st != BTR_OK) return st;
+  if (first > total || count > total - first) return fail(BTR_ERR_INVALID_ARGUMENT, "chunk range outside the part");
+  descs.resize(count);
+  size_t out_pos = 0, row_pos = 0;
+  for (uint32_t k = 0; k < count; k++) {
+    size_t off, len;
+    if ((st = btr_part_chunk(host_part, bytes, first + k, &off, &len)) != BTR_OK) return st;
+    btr_chunk_info info;
+    if ((st = parse_chunk((const uint8_t*)host_part + off, len, &info)) != BTR_OK)
+      return fail(st, "chunk " + std::to_string(first + k) + ": " + g_error);
+    btr_chunk_desc& d = descs[k];
+    d.host_src = (const uint8_t*)host_part + off;
+    d.dev_src = (const uint8_t*)dev_part + off;
+    d.src_bytes = len;
+    d.dev_dst = (uint8_t*)dev_dst + out_pos;
+    d.dst_bytes = info.decoded_bytes;
+    d.dev_nullmap_dst = dev_nullmap_dst ? dev_nullmap_dst + row_pos : nullptr;
+    out_pos += (info.decoded_bytes + 15) / 16 * 16;
+    row_pos += info.tuple_count;
+    if (out_pos - ((info.decoded_bytes + 15) / 16 * 16 - info.decoded_bytes) > dst_bytes)
+      return fail(BTR_ERR_BUFFER_TOO_SMALL, "destination too small for the chunk range");
+    if (dev_nullmap_dst && row_pos > nullmap_bytes) return fail(BTR_ERR_BUFFER_TOO_SMALL, "nullmap destination too small");
+  }
   return BTR_OK;
 }
 
@@ -255,7 +431,7 @@ btr_status finish_plan(btr_gpu_ctx* ctx, std::vector<WorkItem>& items, std::vect
 extern "C" {
 
 const char* btr_last_error(void) { return g_error.c_str(); }
-const char* btr_version(void) { return "btrblocks_amd 0.1 (gfx950)"; }
+const char* btr_version(void) { return "btrblocks_amd 0.2 (gfx950)"; }
 const char* btr_kernel_name(uint32_t k) {
   static const char* const names[KERNEL_KINDS] = {
       "btr_decode_int_kernel",      "btr_decode_dbl_kernel",      "btr_stream_none_kernel",  "btr_stream_add_kernel",
@@ -283,6 +459,10 @@ btr_status btr_chunk_describe(const void* chunk, size_t bytes, char* out, size_t
     snprintf(out, cap, "%s", bp.description.c_str());
   } catch (const PlanError& e) {
     return fail((btr_status)e.status, e.what());
+  } catch (const std::bad_alloc&) {
+    return fail(BTR_ERR_OUT_OF_MEMORY, "out of host memory");
+  } catch (const std::exception& e) {
+    return fail(BTR_ERR_CORRUPT, e.what());
   }
   return BTR_OK;
 }
@@ -311,6 +491,23 @@ btr_status btr_part_chunk(const void* part, size_t bytes, uint32_t index, size_t
   return BTR_OK;
 }
 
+btr_status btr_part_inspect(const void* part, size_t bytes, uint32_t first, uint32_t count, btr_chunk_info* infos,
+                            uint64_t* offsets, uint64_t* lengths) {
+  uint32_t total;
+  btr_status st = btr_part_chunk_count(part, bytes, &total);
+  if (st != BTR_OK) return st;
+  if (first > total || count > total - first) return fail(BTR_ERR_INVALID_ARGUMENT, "chunk range outside the part");
+  for (uint32_t k = 0; k < count; k++) {
+    size_t off, len;
+    if ((st = btr_part_chunk(part, bytes, first + k, &off, &len)) != BTR_OK) return st;
+    if (offsets) offsets[k] = off;
+    if (lengths) lengths[k] = len;
+    if (infos && (st = parse_chunk((const uint8_t*)part + off, len, &infos[k])) != BTR_OK)
+      return fail(st, "chunk " + std::to_string(first + k) + ": " + g_error);
+  }
+  return BTR_OK;
+}
+
 btr_status btr_datablock_inspect(const void* block, size_t bytes, uint32_t* tuple_count, uint32_t* column_count) {
   if (!block) return fail(BTR_ERR_INVALID_ARGUMENT, "null argument");
   if (bytes < DB_ATTRS) return fail(BTR_ERR_CORRUPT, "block shorter than its header");
@@ -324,7 +521,6 @@ btr_status btr_datablock_column(const void* block, size_t bytes, uint32_t column
   if (!block || !out) return fail(BTR_ERR_INVALID_ARGUMENT, "null argument");
   return parse_block_column((const uint8_t*)block, bytes, column, out, nullptr, nullptr);
 }
-
 // ---- compression (CPU) ----------------------------------------------------------------------------
 size_t btr_compress_bound(uint8_t column_type, uint32_t n) {
   const size_t elem = column_type == COL_DOUBLE ? 8 : 4;
@@ -447,24 +643,26 @@ btr_status btr_compress_column(uint8_t column_type, const void* values, const ui
 }
 
 // ---- GPU ----------------------------------------------------------------------------------------------
+static const void* const kAllKernels[KERNEL_KINDS] = {
+    (const void*)btr_decode_int_kernel,         (const void*)btr_decode_dbl_kernel,
+    (const void*)btr_stream_none_kernel,        (const void*)btr_stream_add_kernel,
+    (const void*)btr_stream_dict_lds_kernel,    (const void*)btr_stream_dict_glb_kernel,
+    (const void*)btr_stream_pseudo_kernel,      (const void*)btr_stream_dictd_kernel,
+    (const void*)btr_decode_int_pfor_kernel,    (const void*)btr_decode_dbl_pfor_kernel,
+    (const void*)btr_stream_none_nm_kernel,     (const void*)btr_stream_add_nm_kernel,
+    (const void*)btr_stream_dict_lds_nm_kernel, (const void*)btr_stream_dict_glb_nm_kernel,
+    (const void*)btr_stream_pseudo_nm_kernel,   (const void*)btr_stream_dictd_nm_kernel};
+
 btr_status btr_gpu_ctx_create(int device, btr_gpu_ctx** out) {
   if (!out) return fail(BTR_ERR_INVALID_ARGUMENT, "null argument");
   int count = 0;
   hipError_t e = hipGetDeviceCount(&count);
   if (e != hipSuccess || count == 0)
     return fail(BTR_ERR_DEVICE, "no HIP device available: decoding requires an MI355X (gfx950) GPU");
-  if (device < 0 || device >= count) return fail(BTR_ERR_INVALID_ARGUMENT, "device index out of range");
+  if (device < 0 || device >= count ) return fail(BTR_ERR_INVALID_ARGUMENT, "device index out of range");
   DeviceGuard guard(device);
   if (!guard.ok) return fail(BTR_ERR_DEVICE, "hipSetDevice failed");
-  const void* kernels[] = {(const void*)btr_decode_int_kernel,      (const void*)btr_decode_dbl_kernel,
-                           (const void*)btr_stream_none_kernel,     (const void*)btr_stream_add_kernel,
-                           (const void*)btr_stream_dict_lds_kernel, (const void*)btr_stream_dict_glb_kernel,
-                           (const void*)btr_stream_pseudo_kernel,   (const void*)btr_stream_dictd_kernel,
-                           (const void*)btr_decode_int_pfor_kernel, (const void*)btr_decode_dbl_pfor_kernel,
-                           (const void*)btr_stream_none_nm_kernel,  (const void*)btr_stream_add_nm_kernel,
-                           (const void*)btr_stream_dict_lds_nm_kernel, (const void*)btr_stream_dict_glb_nm_kernel,
-                           (const void*)btr_stream_pseudo_nm_kernel, (const void*)btr_stream_dictd_nm_kernel};
-  for (const void* k : kernels) {
+  for (const void* k : kAllKernels) {
     hipFuncAttributes attr;
     e = hipFuncGetAttributes(&attr, k);
     // blocks with many rows need more than the default 64 KiB of dynamic LDS
@@ -482,83 +680,23 @@ void btr_gpu_ctx_destroy(btr_gpu_ctx* ctx) { delete ctx; }
 
 btr_status btr_gpu_plan_create(btr_gpu_ctx* ctx, const btr_chunk_desc* chunks, size_t n, btr_gpu_plan** out) {
   if (!ctx || (!chunks && n) || !out) return fail(BTR_ERR_INVALID_ARGUMENT, "null argument");
-  std::vector<WorkItem> items(n);
-  std::vector<BuiltProgram> progs(n);
-  std::vector<uint8_t> is_double(n, 0);
-  std::vector<btr_chunk_info> infos(n);
-  // Header walk and validation of one chunk; chunks are independent, so large plans are compiled on
-  // several host threads (the first failing chunk is the one reported).
-  auto compile = [&](size_t i, std::string& err) -> btr_status {
-    const btr_chunk_desc& d = chunks[i];
-    if (!d.host_src || !d.dev_src || !d.dev_dst) {
-      err = "null pointer";
-      return BTR_ERR_INVALID_ARGUMENT;
-    }
-    btr_chunk_info& info = infos[i];
-    btr_status st = parse_chunk((const uint8_t*)d.host_src, d.src_bytes, &info);
-    if (st != BTR_OK) {
-      err = g_error;
-      return st;
-    }
-    if (d.dst_bytes < info.decoded_bytes) {
-      err = "destination too small";
-      return BTR_ERR_BUFFER_TOO_SMALL;
-    }
-    if ((uint64_t)(uintptr_t)d.dev_dst % 8 != 0) {
-      err = "destination must be 8-byte aligned";
-      return BTR_ERR_MISALIGNED;
-    }
-    try {
-      build_program(chunk_source((const uint8_t*)d.host_src, d.src_bytes, (uint64_t)(uintptr_t)d.dev_src, info,
-                                 d.dev_nullmap_dst != nullptr),
-                    progs[i]);
-    } catch (const PlanError& e) {
-      err = e.what();
-      return (btr_status)e.status;
-    }
-    WorkItem& it = items[i];
-    it.src = (uint64_t)(uintptr_t)d.dev_src;
-    it.dst = (uint64_t)(uintptr_t)d.dev_dst;
-    it.nullmap_dst = (uint64_t)(uintptr_t)d.dev_nullmap_dst;
-    it.tuple_count = info.tuple_count;
-    it.src_bytes = (uint32_t)d.src_bytes;
-    is_double[i] = info.column_type == COL_DOUBLE;
-    return BTR_OK;
-  };
-  const size_t hw = std::max(1u, std::thread::hardware_concurrency());
-  const size_t workers = n < 256 ? 1 : std::min<size_t>({hw, 16, n / 128});
-  std::vector<size_t> bad_at(workers, n);
-  std::vector<btr_status> bad_status(workers, BTR_OK);
-  std::vector<std::string> bad_text(workers);
-  auto run = [&](size_t w) {
-    const size_t lo = n * w / workers, hi = n * (w + 1) / workers;
-    for (size_t i = lo; i < hi; i++) {
-      const btr_status st = compile(i, bad_text[w]);
-      if (st != BTR_OK) {
-        bad_at[w] = i;
-        bad_status[w] = st;
-        return;
-      }
-    }
-  };
-  if (workers == 1) {
-    run(0);
-  } else {
-    std::vector<std::thread> pool;
-    for (size_t w = 0; w < workers; w++) pool.emplace_back(run, w);
-    for (auto& t : pool) t.join();
+  return create_plan(ctx, chunks, n, out);
+}
+
+btr_status btr_gpu_plan_create_part(btr_gpu_ctx* ctx, const void* host_part, const void* dev_part, size_t bytes,
+                                    uint32_t first_chunk, uint32_t chunk_count, void* dev_dst, size_t dst_bytes,
+                                    uint8_t* dev_nullmap_dst, size_t nullmap_bytes, btr_gpu_plan** out) {
+  if (!ctx || !host_part || !dev_part || (!dev_dst && chunk_count) || !out) return fail(BTR_ERR_INVALID_ARGUMENT, "null argument");
+  std::vector<btr_chunk_desc> descs;
+  btr_status st;
+  try {
+    st = part_descs(host_part, dev_part, bytes, first_chunk, chunk_count, dev_dst, dst_bytes, dev_nullmap_dst,
+                    nullmap_bytes, descs);
+  } catch (const std::bad_alloc&) {
+    return fail(BTR_ERR_OUT_OF_MEMORY, "out of host memory");
   }
-  for (size_t w = 0; w < workers; w++)  // ranges are in chunk order: the first failure is the lowest index
-    if (bad_status[w] != BTR_OK) return fail(bad_status[w], "chunk " + std::to_string(bad_at[w]) + ": " + bad_text[w]);
-  btr_plan_stats stats{};
-  for (size_t i = 0; i < n; i++) {
-    stats.tuples += infos[i].tuple_count;
-    stats.decoded_bytes += infos[i].decoded_bytes;
-    stats.stored_bytes += chunks[i].src_bytes;
-    stats.needed_bytes += CHUNK_DATA;
-    if (chunks[i].dev_nullmap_dst) stats.nullmap_bytes += infos[i].tuple_count;
-  }
-  return finish_plan(ctx, items, progs, is_double, stats, out);
+  if (st != BTR_OK) return st;
+  return create_plan(ctx, descs.data(), descs.size(), out);
 }
 
 btr_status btr_gpu_plan_create_datablock(btr_gpu_ctx* ctx, const void* host_block, const void* dev_block,
@@ -570,9 +708,10 @@ btr_status btr_gpu_plan_create_datablock(btr_gpu_ctx* ctx, const void* host_bloc
   btr_status st = btr_datablock_inspect(host_block, bytes, &n, &cols);
   if (st != BTR_OK) return st;
   if (cols != column_count) return fail(BTR_ERR_INVALID_ARGUMENT, "column_count does not match the block");
+  if (bytes > 0xFFFFFFFFull) return fail(BTR_ERR_UNSUPPORTED, "block above 4 GiB");
+  const double t0 = now_s();
   std::vector<WorkItem> items(cols);
   std::vector<BuiltProgram> progs(cols);
-  std::vector<uint8_t> is_double(cols, 0);
   btr_plan_stats stats{};
   stats.stored_bytes = bytes;
   stats.needed_bytes = DB_ATTRS + (uint64_t)DB_ATTR_BYTES * cols;
@@ -584,6 +723,8 @@ btr_status btr_gpu_plan_create_datablock(btr_gpu_ctx* ctx, const void* host_bloc
     if (info.column_type != COL_INTEGER && info.column_type != COL_DOUBLE)
       return fail(BTR_ERR_UNSUPPORTED, "column " + std::to_string(c) + ": only integer and double columns are decoded");
     if (!dsts[c]) return fail(BTR_ERR_INVALID_ARGUMENT, "column " + std::to_string(c) + ": null destination");
+    if ((uint64_t)(uintptr_t)dsts[c] % 8 != 0)
+      return fail(BTR_ERR_MISALIGNED, "column " + std::to_string(c) + ": destination must be 8-byte aligned");
     ColumnSource cs{};
     cs.host = hb;
     cs.bytes = bytes;
@@ -599,6 +740,10 @@ btr_status btr_gpu_plan_create_datablock(btr_gpu_ctx* ctx, const void* host_bloc
       build_program(cs, progs[c]);
     } catch (const PlanError& e) {
       return fail((btr_status)e.status, "column " + std::to_string(c) + ": " + e.what());
+    } catch (const std::bad_alloc&) {
+      return fail(BTR_ERR_OUT_OF_MEMORY, "out of host memory while compiling the decode program");
+    } catch (const std::exception& e) {
+      return fail(BTR_ERR_CORRUPT, "column " + std::to_string(c) + ": " + e.what());
     }
     WorkItem& it = items[c];
     it.src = (uint64_t)(uintptr_t)dev_block;
@@ -606,12 +751,12 @@ btr_status btr_gpu_plan_create_datablock(btr_gpu_ctx* ctx, const void* host_bloc
     it.nullmap_dst = cs.want_nullmap ? (uint64_t)(uintptr_t)nullmap_dsts[c] : 0;
     it.tuple_count = n;
     it.src_bytes = (uint32_t)bytes;
-    is_double[c] = info.column_type == COL_DOUBLE;
     stats.tuples += n;
     stats.decoded_bytes += info.decoded_bytes;
     if (cs.want_nullmap) stats.nullmap_bytes += n;
   }
-  return finish_plan(ctx, items, progs, is_double, stats, out);
+  stats.compile_seconds = now_s() - t0;
+  return finish_plan(ctx, items, progs, stats, out);
 }
 
 void btr_gpu_plan_destroy(btr_gpu_plan* plan) {

@@ -2960,7 +2960,9 @@ __device__ __forceinline__ void decode_block(const WorkItem* __restrict__ items,
   stamp(it, 1);
 
   // bit-unpack indexes: one stream per wave, streams in parallel
+#ifdef BTR_DEBUG_STEPS
   if (!(it.debug_flags & 5))
+#endif
     for (u32 s = uniform(tid >> 6); s < hdr.n_bp_steps; s += kBlockThreads / 64)
       bp_index_wave(c, step_at(c, s));
   __syncthreads();
@@ -2968,9 +2970,11 @@ __device__ __forceinline__ void decode_block(const WorkItem* __restrict__ items,
 
   for (u32 s = hdr.n_bp_steps; s < hdr.n_steps; s++) {
     const Step& st = step_at(c, s);
+#ifdef BTR_DEBUG_STEPS  // step skipping leaves the column undecoded: diagnostic builds only
     if ((it.debug_flags & 2) && s + 1 == hdr.n_steps) break;
     if ((it.debug_flags & 4) && s + 1 != hdr.n_steps) continue;  // root step only, over whatever LDS holds
     if ((it.debug_flags >> 8) && s - hdr.n_bp_steps + 1 >= (it.debug_flags >> 8)) break;  // stop after k-1 steps
+#endif
     switch (uniform(st.kind)) {
       case S_MATERIALIZE: materialize<DOUBLE_KERNEL>(c, uniform(st.a[0]), uniform(st.a[1])); break;
       case S_BITMAP_CLEAR: bitmap_clear(c, st); break;

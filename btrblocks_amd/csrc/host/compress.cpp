@@ -164,6 +164,28 @@ struct Stats {
   double avg_run_length = 0;
 };
 
+// Total order behind the distinct-value tables: numbers by value (so -0.0 and 0.0 share an entry,
+// like the reference's std::map), NaNs after every number and among themselves by bit pattern.
+// The reference's map is undefined for NaN; here a NaN row keeps its exact bits.
+template <typename T>
+inline bool value_less(T a, T b) {
+  if constexpr (sizeof(T) == 8) {
+    const bool an = a != a, bn = b != b;
+    if (an || bn) {
+      if (!(an && bn)) return bn;
+      uint64_t x, y;
+      memcpy(&x, &a, 8);
+      memcpy(&y, &b, 8);
+      return x < y;
+    }
+  }
+  return a < b;
+}
+template <typename T>
+inline bool value_same(T a, T b) {
+  return !value_less(a, b) && !value_less(b, a);
+}
+
 // Mirrors NumberStats<T>::generateStats (btrblocks/stats/NumberStats.hpp:78-130): values at null
 // rows take part in distinct/min/max; a run only breaks at a non-null row with a new value.
 template <typename T>
@@ -172,11 +194,10 @@ Stats<T> make_stats(const T* src, const uint8_t* nm, uint32_t n) {
   s.n = n;
   if (n == 0) return s;
   std::vector<T> sorted(src, src + n);
-  std::sort(sorted.begin(), sorted.end(), [](T a, T b) { return a < b; });
+  std::sort(sorted.begin(), sorted.end(), value_less<T>);
   for (uint32_t i = 0; i < n;) {
     uint32_t j = i;
-    while (j < n && sorted[j] == sorted[i]) j++;
-    if (j == i) j = i + 1;  // NaN never equals itself
+    while (j < n && value_same(sorted[j], sorted[i])) j++;
     s.distinct.push_back(sorted[i]);
     s.counts.push_back(j - i);
     i = j;
@@ -264,7 +285,7 @@ void emit_rle(Writer& w, const Ctx& cx, const T* src, const uint8_t* nm, uint32_
   T last = src[0];
   int32_t count = 1;
   for (uint32_t i = 1; i < n; i++) {
-    if (src[i] == last || (nm != nullptr && !nm[i])) {
+    if (value_same(src[i], last) || (nm != nullptr && !nm[i])) {
       count++;
     } else {
       counts.push_back(count);
@@ -306,8 +327,7 @@ void emit_dict(Writer& w, const Ctx& cx, const T* src, uint32_t n, int level, co
   w.put(st.distinct.data(), st.distinct.size() * sizeof(T));
   std::vector<int32_t> codes(n);
   for (uint32_t i = 0; i < n; i++) {
-    auto it = std::lower_bound(st.distinct.begin(), st.distinct.end(), src[i],
-                               [](T a, T b) { return a < b; });
+    auto it = std::lower_bound(st.distinct.begin(), st.distinct.end(), src[i], value_less<T>);
     codes[i] = (int32_t)(it - st.distinct.begin());
   }
   wr32(w.at(hdr + DICT_CODES_OFFSET), (uint32_t)(w.pos() - data));
@@ -337,7 +357,7 @@ void emit_frequency(Writer& w, const Ctx& cx, const T* src, const uint8_t* nm, u
   std::vector<T> exceptions;
   std::vector<uint32_t> rows;
   for (uint32_t i = 0; i < n; i++)
-    if (src[i] != top && (nm == nullptr || nm[i])) exceptions.push_back(src[i]), rows.push_back(i);
+    if (!value_same(src[i], top) && (nm == nullptr || nm[i])) exceptions.push_back(src[i]), rows.push_back(i);
   memcpy(w.at(hdr), &top, sizeof(T));
   const size_t data = w.pos();
   roaring_serialize(rows.data(), rows.size(), w.buf);
@@ -359,8 +379,7 @@ void emit_fixed_dict(Writer& w, const T* src, uint32_t n, const Stats<T>& st) {
   w.put(st.distinct.data(), st.distinct.size() * sizeof(T));
   wr32(w.at(hdr + FDICT_CODES_OFFSET), (uint32_t)(w.pos() - hdr));
   for (uint32_t i = 0; i < n; i++) {
-    auto it = std::lower_bound(st.distinct.begin(), st.distinct.end(), src[i],
-                               [](T a, T b) { return a < b; });
+    auto it = std::lower_bound(st.distinct.begin(), st.distinct.end(), src[i], value_less<T>);
     Code c = (Code)(it - st.distinct.begin());
     w.put(&c, sizeof(Code));
   }

@@ -127,8 +127,9 @@ struct WorkItem {
   uint32_t prog_bytes;
   uint32_t tuple_count;
   uint32_t src_bytes;
-  uint32_t debug_flags;  // diagnostics only (BTR_DEBUG_FLAGS): 1 = skip index walks, 2 = skip the root step,
-                         // 4 = root step only, 8 = record step timestamps, k << 8 = stop before step k
+  uint32_t debug_flags;  // diagnostics only (BTR_DEBUG_FLAGS): 8 = record step timestamps; in builds with
+                         // -DBTR_DEBUG_STEPS also 1 = skip index walks, 2 = skip the root step,
+                         // 4 = root step only, k << 8 = stop before step k
   uint32_t pad;
   uint64_t debug_buf;    // flag 8: kDebugSlots 100 MHz timestamps of this item
 };

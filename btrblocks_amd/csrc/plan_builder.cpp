@@ -32,6 +32,7 @@ constexpr int kMaxDepth = 8;
 constexpr uint32_t kLdsSoftCapGeneric = 52 * 1024;  // three workgroups per CU
 constexpr uint32_t kLdsSoftCapStream = 60 * 1024;   // two 512-thread workgroups per CU when a dictionary needs it
 constexpr uint32_t kDictLdsMaxBytes = 32 * 1024;
+constexpr uint32_t kMaxTupleCount = 1u << 24;
 
 struct Builder {
   const ColumnSource& cs;
@@ -586,13 +587,20 @@ struct Builder {
   }
 };
 
-uint32_t align_up(uint32_t v, uint32_t a) { return (v + a - 1) / a * a; }
+uint64_t align_up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
+// Table sizes come from untrusted counts: always 64-bit products.
+uint64_t seq_bytes(const Seq& s) { return align_up((uint64_t)s.count * s.esize, 16); }
 
 }  // namespace
 
 void build_program(const ColumnSource& src, BuiltProgram& out) {
   if (src.column_type != COL_INTEGER && src.column_type != COL_DOUBLE)
     throw PlanError(ST_UNSUPPORTED, "only integer and double columns are decoded on the GPU");
+  // Blocks hold at most 65536 rows in column part files (btrblocks.hpp:24) and a few hundred
+  // thousand in relation-level blocks; far larger counts only come from damaged headers.
+  if (src.tuple_count > kMaxTupleCount)
+    throw PlanError(ST_UNSUPPORTED, "tuple count above " + std::to_string(kMaxTupleCount) + " rows per block");
+  if (src.bytes > 0xFFFFFFFFull) throw PlanError(ST_UNSUPPORTED, "compressed block above 4 GiB");
   Builder bld{src, {}, {}, {}, {}, {}, {}, {}, 0, 0};
   const uint32_t n = src.tuple_count;
   std::string desc;
@@ -711,11 +719,12 @@ void build_program(const ColumnSource& src, BuiltProgram& out) {
   const size_t n_steps = bld.bp_steps.size() + bld.steps.size();
   const size_t prog_bytes = sizeof(ProgramHeader) + n_steps * sizeof(Step) + bld.pipes.size() * sizeof(Pipe) +
                             bld.seqs.size() * sizeof(Seq) + bld.consts.size() * 4;
-  const uint32_t table_base = prog_base + align_up((uint32_t)prog_bytes, 16) + 64;  // + reduction scratch
+  if (prog_bytes > kLdsCapBytes) throw PlanError(ST_UNSUPPORTED, "decode program of this chunk exceeds the LDS budget");
+  const uint32_t table_base = prog_base + (uint32_t)align_up(prog_bytes, 16) + 64;  // + reduction scratch
   if (ring_bits != NONE) {
     // offsets are relative to the table base: these two wrap around to LDS addresses 0.. (the ring)
     bld.seqs[ring_bits].off = 0u - table_base;
-    bld.seqs[ring_rank].off = (uint32_t)align_up(bld.seqs[ring_bits].count * 8, 16) - table_base;
+    bld.seqs[ring_rank].off = (uint32_t)align_up((uint64_t)bld.seqs[ring_bits].count * 8, 16) - table_base;
   }
   uint64_t lds = 0, scratch = 0;
   auto place_tables = [&]() {
@@ -723,13 +732,13 @@ void build_program(const ColumnSource& src, BuiltProgram& out) {
     for (auto& s : bld.seqs)
       if (s.loc == LOC_LDS && s.must_lds && s.must_lds != 3) {
         s.off = (uint32_t)lds;
-        lds += align_up(s.count * s.esize, 16);
+        lds += seq_bytes(s);
       }
     if (table_base + lds > kLdsCapBytes && kernel_is_generic(kernel)) {
       // very large blocks: give up the walkers' jump tables (they only speed the index steps up)
       for (uint32_t k = 0; k < 4; k++)
         if (walk_scratch[k] != NONE) {
-          lds -= align_up(bld.seqs[walk_scratch[k]].count * bld.seqs[walk_scratch[k]].esize, 16);
+          lds -= seq_bytes(bld.seqs[walk_scratch[k]]);
           bld.seqs[walk_scratch[k]].count = 0;
         }
       for (Step& st : bld.bp_steps) st.a[1] = NONE;
@@ -737,13 +746,13 @@ void build_program(const ColumnSource& src, BuiltProgram& out) {
       for (auto& s : bld.seqs)
         if (s.loc == LOC_LDS && s.must_lds && s.must_lds != 3) {
           s.off = (uint32_t)lds;
-          lds += align_up(s.count * s.esize, 16);
+          lds += seq_bytes(s);
         }
     }
     {
       // one shared region for the transient tables, sized for the largest
       uint64_t shared = 0;
-      for (uint32_t id : bld.transient) shared = std::max<uint64_t>(shared, align_up(bld.seqs[id].count * bld.seqs[id].esize, 16));
+      for (uint32_t id : bld.transient) shared = std::max<uint64_t>(shared, seq_bytes(bld.seqs[id]));
       const uint32_t cap = kernel_is_generic(kernel) ? kLdsSoftCapGeneric : kLdsSoftCapStream;
       if (shared && table_base + lds + shared <= cap) {
         for (uint32_t id : bld.transient) {
@@ -755,7 +764,7 @@ void build_program(const ColumnSource& src, BuiltProgram& out) {
     }
     for (auto& s : bld.seqs)
       if (s.loc == LOC_LDS && !s.must_lds) {
-        const uint64_t bytes = align_up(s.count * s.esize, 16);
+        const uint64_t bytes = seq_bytes(s);
         if (table_base + lds + bytes <= (kernel_is_generic(kernel) ? kLdsSoftCapGeneric : kLdsSoftCapStream)) {
           s.off = (uint32_t)lds;
           lds += bytes;
@@ -775,7 +784,7 @@ void build_program(const ColumnSource& src, BuiltProgram& out) {
     // that region: the root step gathers from LDS instead of the scratch slice.
     const uint32_t region_off = bld.seqs[bld.transient[0]].off;
     uint64_t region_bytes = 0;
-    for (uint32_t id : bld.transient) region_bytes = std::max<uint64_t>(region_bytes, align_up(bld.seqs[id].count * bld.seqs[id].esize, 16));
+    for (uint32_t id : bld.transient) region_bytes = std::max<uint64_t>(region_bytes, seq_bytes(bld.seqs[id]));
     auto is_transient = [&](uint32_t id) { return std::find(bld.transient.begin(), bld.transient.end(), id) != bld.transient.end(); };
     std::function<void(uint32_t, std::vector<uint32_t>&)> reads = [&](uint32_t pipe, std::vector<uint32_t>& out) {
       if (pipe == NONE) return;
@@ -803,9 +812,9 @@ void build_program(const ColumnSource& src, BuiltProgram& out) {
     size_t best_step = 0;
     for (uint32_t id = 0; id < bld.seqs.size() && root_idx < bld.steps.size(); id++) {
       const Seq& sq = bld.seqs[id];
-      const uint64_t bytes = align_up(sq.count * sq.esize, 16);
+      const uint64_t bytes = seq_bytes(sq);
       if (sq.loc != LOC_SCRATCH || bytes == 0 || bytes > region_bytes) continue;
-      if (best != NONE && bytes <= align_up(bld.seqs[best].count * bld.seqs[best].esize, 16)) continue;
+      if (best != NONE && bytes <= seq_bytes(bld.seqs[best])) continue;
       size_t producer = bld.steps.size(), producers = 0;
       bool movable = true;
       for (size_t k = 0; k < bld.steps.size(); k++) {
@@ -839,7 +848,7 @@ void build_program(const ColumnSource& src, BuiltProgram& out) {
       bld.seqs[best].off = region_off;
       scratch = 0;  // the scratch slice ends behind the last table left in it
       for (const Seq& sq : bld.seqs)
-        if (sq.loc == LOC_SCRATCH) scratch = std::max<uint64_t>(scratch, sq.off + align_up(sq.count * sq.esize, 16));
+        if (sq.loc == LOC_SCRATCH) scratch = std::max<uint64_t>(scratch, sq.off + seq_bytes(sq));
     }
   }
   size_t stream_root = bld.steps.size() - 1;  // a constant-nullmap step may follow the streamed root

@@ -22,17 +22,17 @@ class BtrReader:
         self.ctx = ctx or api.GpuContext(device)
         self.device = torch.device("cuda", self.ctx.device)
         self.image = api._as_u8(data)
-        self.chunks = api.part_chunks(self.image)
-        self.infos = [api.chunk_info(self.image[o:o + n]) for o, n in self.chunks]
+        self.infos, offsets, lengths = api.part_inspect(self.image)  # one call for all envelopes
+        self.chunks = list(zip(offsets.tolist(), lengths.tolist()))
         self.d_image = torch.from_numpy(self.image).to(self.device)
-        # decoded column: chunks back to back, each start 16-byte aligned
-        self.out_offsets = []
-        pos = 0
-        for info in self.infos:
-            self.out_offsets.append(pos)
-            pos += (info.decoded_bytes + 15) // 16 * 16
-        self.d_out = torch.empty(max(pos, 16), dtype=torch.uint8, device=self.device)
-        self.row_offsets = np.concatenate([[0], np.cumsum([i.tuple_count for i in self.infos])]).astype(np.int64)
+        # decoded column: chunks back to back, each start 16-byte aligned (the layout
+        # btr_gpu_plan_create_part uses)
+        recs = np.frombuffer(self.infos, dtype=np.dtype([("tuple_count", "<u4"), ("t", "u1"), ("s", "u1"), ("n", "u1"),
+                                                          ("r", "u1"), ("decoded_bytes", "<u8")]))
+        padded = (recs["decoded_bytes"].astype(np.int64) + 15) // 16 * 16
+        self.out_offsets = np.concatenate([[0], np.cumsum(padded)]).astype(np.int64)
+        self.d_out = torch.empty(max(int(self.out_offsets[-1]), 16), dtype=torch.uint8, device=self.device)
+        self.row_offsets = np.concatenate([[0], np.cumsum(recs["tuple_count"].astype(np.int64))]).astype(np.int64)
         self.d_nullmap = None
         self._plans = {}
 
@@ -66,7 +66,7 @@ class BtrReader:
         d.host_src = self.image.ctypes.data + o
         d.dev_src = self.d_image.data_ptr() + o
         d.src_bytes = n
-        d.dev_dst = self.d_out.data_ptr() + self.out_offsets[index]
+        d.dev_dst = self.d_out.data_ptr() + int(self.out_offsets[index])
         d.dst_bytes = self.infos[index].decoded_bytes
         d.dev_nullmap_dst = (self.d_nullmap.data_ptr() + int(self.row_offsets[index])) if with_nullmap else None
         return d
@@ -78,8 +78,13 @@ class BtrReader:
             if with_nullmap and self.d_nullmap is None:
                 self.d_nullmap = self._torch.empty(max(int(self.row_offsets[-1]), 16), dtype=self._torch.uint8,
                                                    device=self.device)
-            idx = range(len(self.chunks)) if indices is None else indices
-            self._plans[key] = api.DecodePlan(self.ctx, [self._desc(i, with_nullmap) for i in idx])
+            if indices is None:  # the whole part: one call, no per-chunk descriptors
+                self._plans[key] = api.DecodePlan.for_part(
+                    self.ctx, self.image, self.d_image.data_ptr(), 0, len(self.chunks), self.d_out.data_ptr(),
+                    self.d_out.numel(), self.d_nullmap.data_ptr() if with_nullmap else None,
+                    self.d_nullmap.numel() if with_nullmap else 0, keepalive=(self.d_image, self.d_out, self.d_nullmap))
+            else:
+                self._plans[key] = api.DecodePlan(self.ctx, [self._desc(i, with_nullmap) for i in indices])
         return self._plans[key]
 
     def readColumn(self, index, with_bitmap=False):
@@ -89,7 +94,7 @@ class BtrReader:
         p.decode(api.current_stream_ptr())
         p.check(api.current_stream_ptr())
         info = self.infos[index]
-        o = self.out_offsets[index]
+        o = int(self.out_offsets[index])
         host = self.d_out[o:o + info.decoded_bytes].cpu().numpy().view(_DTYPE[info.column_type]).copy()
         if not with_bitmap:
             return host
@@ -114,7 +119,7 @@ class BtrReader:
         raw = self.d_out.cpu().numpy()
         parts = []
         for i, info in enumerate(self.infos):
-            o = self.out_offsets[i]
+            o = int(self.out_offsets[i])
             parts.append(raw[o:o + info.decoded_bytes].view(_DTYPE[info.column_type]))
         return np.concatenate(parts) if parts else np.empty(0, dtype=np.int32)
 

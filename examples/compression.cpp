@@ -53,6 +53,36 @@ int main(int argc, char** argv) {
               << "- blocks " << ranges.size() << std::endl;
     std::cout << (check ? "decompressed data matches original data" : "decompressed data does not match original data")
               << std::endl;
+
+    // The column-part path the reference's decompression-speed tool times
+    // (tools/conversion/decompression-speed.cpp:40-64): one BtrReader per part image, readColumn per
+    // chunk, getBitmap / releaseBitmap per chunk. Every 7th row of the integer column is null.
+    {
+      const std::vector<int32_t> ints = generateData<int32_t>(size, 1 << 12, 40, 42);
+      std::vector<uint8_t> valid(size, 1);
+      for (size_t i = 0; i < size; i += 7) valid[i] = 0;
+      std::vector<uint8_t> image(btr_compress_column_bound(0, size, 65536));
+      size_t image_bytes = 0;
+      btrblocks_amd::check(btr_compress_column(0, ints.data(), valid.data(), size, 65536, spec.c_str(), nullptr, 0, image.data(),
+                                       image.size(), &image_bytes));
+      BtrReader reader(image.data(), image_bytes);
+      bool part_ok = reader.getChunkCount() == (size + 65535) / 65536;
+      std::vector<u8> chunk;
+      size_t row = 0;
+      for (u32 i = 0; i < reader.getChunkCount(); i++) {
+        const u32 n = reader.getTupleCount(i);
+        part_ok = part_ok && reader.getDecompressedDataSize(i) == (size_t)n * 4 && !reader.readColumn(chunk, i);
+        const BITMAP* bm = reader.getBitmap(i);
+        const int32_t* got = reinterpret_cast<const int32_t*>(chunk.data());
+        for (u32 r = 0; r < n && part_ok; r++)
+          part_ok = bm[r] == valid[row + r] && (!valid[row + r] || got[r] == ints[row + r]);
+        reader.releaseBitmap(i);
+        row += n;
+      }
+      std::cout << (part_ok ? "column part reader matches original data" : "column part reader does not match original data")
+                << std::endl;
+      check = check && part_ok;
+    }
     return check ? 0 : 1;
   } catch (const Generic_Exception& e) {
     std::cerr << "btrblocks_amd error " << e.status << ": " << e.what() << std::endl;

@@ -25,7 +25,7 @@ typedef enum btr_status {
   BTR_OK = 0,
   BTR_ERR_INVALID_ARGUMENT = 1,
   BTR_ERR_CORRUPT = 2,      /* header/offset inconsistent with the supplied byte length          */
-  BTR_ERR_UNSUPPORTED = 3,  /* scheme without a decoder (the reference's Truncation, PFOR here)  */
+  BTR_ERR_UNSUPPORTED = 3,  /* scheme without a decoder (the reference's Truncation), string columns */
   BTR_ERR_BUFFER_TOO_SMALL = 4,
   BTR_ERR_DEVICE = 5,       /* HIP runtime error, no device, or no gfx950 code object            */
   BTR_ERR_MISALIGNED = 6,   /* bit-packed payload not 4-byte aligned at its device address       */
@@ -61,6 +61,11 @@ btr_status btr_chunk_describe(const void* chunk, size_t bytes, char* out, size_t
  * BtrReader::getChunkCount / getChunkMetadata, BtrReader.hpp:28-39. */
 btr_status btr_part_chunk_count(const void* part, size_t bytes, uint32_t* out);
 btr_status btr_part_chunk(const void* part, size_t bytes, uint32_t index, size_t* offset, size_t* length);
+/* Envelopes of chunks [first, first + count) of a part image in one call: what a BtrReader answers
+ * its getters from (BtrReader.hpp:28-39, BtrReader.cpp:159-207). Any of infos / offsets / lengths
+ * may be NULL. */
+btr_status btr_part_inspect(const void* part, size_t bytes, uint32_t first, uint32_t count,
+                            btr_chunk_info* infos, uint64_t* offsets, uint64_t* lengths);
 /* Relation-level block (DatablockMeta + ColumnMeta[], compression/Datablock.hpp:37-55). */
 btr_status btr_datablock_inspect(const void* block, size_t bytes, uint32_t* tuple_count, uint32_t* column_count);
 btr_status btr_datablock_column(const void* block, size_t bytes, uint32_t column, btr_chunk_info* out);
@@ -129,6 +134,15 @@ typedef struct btr_chunk_desc {
  * table placement happen here, not in btr_gpu_decode. */
 btr_status btr_gpu_plan_create(btr_gpu_ctx* ctx, const btr_chunk_desc* chunks, size_t n, btr_gpu_plan** out);
 
+/* Plan over chunks [first_chunk, first_chunk + chunk_count) of a column part image resident on the
+ * device at dev_part: the counterpart of constructing one BtrReader over the part
+ * (BtrReader.hpp:14, BtrReader.cpp:12-15) and calling readColumn for every chunk. Chunk k of the
+ * range decodes to dev_dst + the 16-byte-aligned sizes of the chunks before it; its byte-per-row
+ * nullmap (dev_nullmap_dst may be NULL) to dev_nullmap_dst + the rows before it. */
+btr_status btr_gpu_plan_create_part(btr_gpu_ctx* ctx, const void* host_part, const void* dev_part, size_t bytes,
+                                    uint32_t first_chunk, uint32_t chunk_count, void* dev_dst, size_t dst_bytes,
+                                    uint8_t* dev_nullmap_dst, size_t nullmap_bytes, btr_gpu_plan** out);
+
 /* Plan over one relation-level block: every integer/double column becomes one work item
  * (Datablock::decompress, Datablock.cpp:340-417). dsts[c] / nullmap_dsts[c] are device pointers
  * (nullmap_dsts or its entries may be NULL). */
@@ -149,6 +163,8 @@ typedef struct btr_plan_stats {
   uint32_t max_depth;
   uint32_t kernel_mask;      /* bit k set: the plan launches kernel k (see btr_kernel_name)     */
   uint32_t launches;         /* kernel launches per btr_gpu_decode                              */
+  double compile_seconds;    /* host time of the header walk + program compilation              */
+  double upload_seconds;     /* host time of laying out and uploading programs and work items   */
 } btr_plan_stats;
 btr_status btr_gpu_plan_stats(const btr_gpu_plan* plan, btr_plan_stats* out);
 /* Name of the HIP kernel behind bit k of btr_plan_stats::kernel_mask (as profilers show it), or

@@ -221,78 +221,103 @@ class Datablock {
 };
 
 // Reader over one column part image {u32 num_chunks; u32 offsets[]} + chunks in host memory
-// (compression/BtrReader.hpp:12-45). The image is uploaded once; readColumn decodes one chunk.
+// (compression/BtrReader.hpp:12-45). The image is uploaded once. The first readColumn / getBitmap
+// decodes every chunk of the part in one launch into a device-resident column (one workgroup per
+// chunk); after that readColumn(i) only copies chunk i back to the host.
 class BtrReader {
  public:
   BtrReader(const void* data, size_t bytes, int device = 0) : data_((const u8*)data), bytes_(bytes) {
     check(btr_gpu_ctx_create(device, &ctx_));
     u32 n = 0;
     check(btr_part_chunk_count(data_, bytes_, &n));
-    chunks_.resize(n);
+    infos_.resize(n);
+    offsets_.resize(n);
+    lengths_.resize(n);
+    check(btr_part_inspect(data_, bytes_, 0, n, infos_.data(), offsets_.data(), lengths_.data()));
+    out_off_.assign(n + 1, 0);
+    row_off_.assign(n + 1, 0);
     for (u32 i = 0; i < n; i++) {
-      check(btr_part_chunk(data_, bytes_, i, &chunks_[i].off, &chunks_[i].len));
-      check(btr_chunk_inspect(data_ + chunks_[i].off, chunks_[i].len, &chunks_[i].info));
+      out_off_[i + 1] = out_off_[i] + (infos_[i].decoded_bytes + 15) / 16 * 16;
+      row_off_[i + 1] = row_off_[i] + infos_[i].tuple_count;
     }
+    bitmaps_.resize(n);
     check(btr_gpu_malloc(ctx_, bytes_ + 16, &d_image_));
     check(btr_gpu_upload(ctx_, d_image_, data_, bytes_));
   }
   ~BtrReader() {
+    if (plan_) btr_gpu_plan_destroy(plan_);
+    btr_gpu_free(ctx_, d_out_);
+    btr_gpu_free(ctx_, d_maps_);
     btr_gpu_free(ctx_, d_image_);
     btr_gpu_ctx_destroy(ctx_);
   }
   BtrReader(const BtrReader&) = delete;
   BtrReader& operator=(const BtrReader&) = delete;
 
-  u32 getChunkCount() const { return (u32)chunks_.size(); }
-  u32 getTupleCount(u32 index) const { return chunks_.at(index).info.tuple_count; }
-  ColumnType getColumnType() const { return chunks_.empty() ? ColumnType::INTEGER : (ColumnType)chunks_[0].info.column_type; }
-  size_t getDecompressedSize(u32 index) const { return chunks_.at(index).info.decoded_bytes; }
+  // BtrReader.hpp:20-39
+  u32 getChunkCount() const { return (u32)infos_.size(); }
+  u32 getTupleCount(u32 index) const { return infos_.at(index).tuple_count; }
+  ColumnType getColumnType() const { return infos_.empty() ? ColumnType::INTEGER : (ColumnType)infos_[0].column_type; }
+  size_t getDecompressedSize(u32 index) const { return infos_.at(index).decoded_bytes; }
+  // BtrReader.cpp:186-207: for numbers the value bytes are the whole decoded chunk.
+  size_t getDecompressedDataSize(u32 index) const { return infos_.at(index).decoded_bytes; }
   std::string getSchemeDescription(u32 index) const {
     char buf[512];
-    check(btr_chunk_describe(data_ + chunks_.at(index).off, chunks_[index].len, buf, sizeof buf));
+    check(btr_chunk_describe(data_ + offsets_.at(index), lengths_[index], buf, sizeof buf));
     return buf;
   }
-  // Decodes chunk `index` into output_chunk_v; returns requires_copy (always false: strings only).
-  bool readColumn(std::vector<u8>& output_chunk_v, u32 index, std::vector<BITMAP>* bitmap = nullptr) {
-    const Part& p = chunks_.at(index);
-    output_chunk_v.resize(p.info.decoded_bytes);
-    void *d_out = nullptr, *d_map = nullptr;
-    btr_gpu_plan* plan = nullptr;
-    auto release = [&]() {
-      if (plan) btr_gpu_plan_destroy(plan);
-      btr_gpu_free(ctx_, d_out);
-      btr_gpu_free(ctx_, d_map);
-    };
-    try {
-      check(btr_gpu_malloc(ctx_, p.info.decoded_bytes + 16, &d_out));
-      if (bitmap) check(btr_gpu_malloc(ctx_, (size_t)p.info.tuple_count + 16, &d_map));
-      btr_chunk_desc d{data_ + p.off, (const u8*)d_image_ + p.off, p.len, d_out, (size_t)p.info.decoded_bytes, (u8*)d_map};
-      check(btr_gpu_plan_create(ctx_, &d, 1, &plan));
-      check(btr_gpu_decode(ctx_, plan, nullptr));
-      check(btr_gpu_plan_check(ctx_, plan, nullptr, nullptr, nullptr));
-      check(btr_gpu_download(ctx_, output_chunk_v.data(), d_out, p.info.decoded_bytes));
-      if (bitmap) {
-        bitmap->resize(p.info.tuple_count);
-        check(btr_gpu_download(ctx_, bitmap->data(), d_map, p.info.tuple_count));
-      }
-    } catch (...) {
-      release();
-      throw;
+  // Byte-per-row validity of chunk `index` (1 = valid), what BitmapWrapper::writeBITMAP produces
+  // (BtrReader.cpp:124-141, extern/RoaringBitmap.cpp:32-53). Owned by the reader until
+  // releaseBitmap(index) (BtrReader.cpp:143-157).
+  const BITMAP* getBitmap(u32 index) {
+    std::vector<BITMAP>& b = bitmaps_.at(index);
+    if (b.empty() && infos_[index].tuple_count) {
+      decodeAll(true);
+      b.resize(infos_[index].tuple_count);
+      check(btr_gpu_download(ctx_, b.data(), (const u8*)d_maps_ + row_off_[index], b.size()));
     }
-    release();
+    return b.data();
+  }
+  void releaseBitmap(u32 index) { std::vector<BITMAP>().swap(bitmaps_.at(index)); }
+
+  // Decodes every chunk of the part in one launch (no-op when already done).
+  void decodeAll(bool with_bitmaps = false) {
+    if (plan_ && (!with_bitmaps || d_maps_)) return;
+    if (plan_) {
+      btr_gpu_plan_destroy(plan_);
+      plan_ = nullptr;
+    }
+    if (!d_out_) check(btr_gpu_malloc(ctx_, out_off_.back() + 16, &d_out_));
+    if (with_bitmaps && !d_maps_) check(btr_gpu_malloc(ctx_, row_off_.back() + 16, &d_maps_));
+    check(btr_gpu_plan_create_part(ctx_, data_, d_image_, bytes_, 0, getChunkCount(), d_out_, out_off_.back() + 16,
+                                   (u8*)d_maps_, d_maps_ ? row_off_.back() + 16 : 0, &plan_));
+    check(btr_gpu_decode(ctx_, plan_, nullptr));
+    check(btr_gpu_plan_check(ctx_, plan_, nullptr, nullptr, nullptr));
+  }
+  // Device address of decoded chunk `index` (after decodeAll).
+  const void* deviceColumn(u32 index) const { return d_out_ ? (const u8*)d_out_ + out_off_.at(index) : nullptr; }
+
+  // Chunk `index` into output_chunk_v (BtrReader.cpp:31-74); returns requires_copy (always
+  // false: strings only). The vector is grown, never shrunk (common/Units.hpp:125-129).
+  bool readColumn(std::vector<u8>& output_chunk_v, u32 index) {
+    const size_t need = infos_.at(index).decoded_bytes;
+    decodeAll(false);
+    if (output_chunk_v.size() < need) output_chunk_v.resize(need);
+    check(btr_gpu_download(ctx_, output_chunk_v.data(), (const u8*)d_out_ + out_off_[index], need));
     return false;
   }
 
  private:
-  struct Part {
-    size_t off = 0, len = 0;
-    btr_chunk_info info{};
-  };
   const u8* data_;
   size_t bytes_;
   btr_gpu_ctx* ctx_ = nullptr;
   void* d_image_ = nullptr;
-  std::vector<Part> chunks_;
+  void* d_out_ = nullptr;
+  void* d_maps_ = nullptr;
+  btr_gpu_plan* plan_ = nullptr;
+  std::vector<btr_chunk_info> infos_;
+  std::vector<uint64_t> offsets_, lengths_, out_off_, row_off_;
+  std::vector<std::vector<BITMAP>> bitmaps_;
 };
 
 }  // namespace btrblocks_amd

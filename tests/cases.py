@@ -138,6 +138,24 @@ def cases():
     for n in (0, 1, 3, 4, 5, 63, 64, 65, 257, 16960):
         add(f"dbl_pseudo_n{n}", synth.double_decimal(max(n, 1), patch_fraction=0.05)[:n], "pseudodecimal(bp,bp,uncompressed)")
         add(f"dbl_dict_n{n}", synth.dictionary_values(max(n, 1), 50, dtype=np.float64)[:n], "dict(bp)")
+    # NaN (several payloads), infinities and signed zeros: every scheme keeps their bits (the
+    # reference's std::map-based statistics are undefined for NaN; value-equality schemes may
+    # merge -0.0 with 0.0)
+    special = np.array([np.nan, -np.nan, np.inf, -np.inf, 0.0, 1.5, -2.25], dtype=np.float64)
+    special_bits = special.view(np.uint64).copy()
+    special_bits[1] = 0x7FF0000000000001  # a signalling NaN pattern
+    special = special_bits.view(np.float64)
+    sp = special[_rng(70).integers(0, special.size, N)]
+    sp_runs = np.repeat(special[_rng(71).integers(0, special.size, N // 16)], 16)
+    for spec in ("auto", "dict(bp)", "dict8", "dict16", "frequency(uncompressed)", "rle(uncompressed,bp)",
+                 "pseudodecimal(bp,bp,uncompressed)", "uncompressed"):
+        add(f"dbl_special_{spec.split('(')[0]}", sp_runs if spec.startswith("rle") else sp, spec)
+    add("dbl_special_mostly_nan", np.where(_rng(72).random(N) < 0.97, np.nan, sp), "frequency(dict(bp))")
+    add("dbl_onevalue_nan", np.full(N, np.nan), "auto")
+    add("dbl_pseudo_special_patches", np.where(_rng(73).random(N) < 0.03, sp, synth.double_decimal(N, patch_fraction=0)),
+        "pseudodecimal(bp,bp,uncompressed)")
+    add("dbl_pseudo_special_patches_dict", np.where(_rng(74).random(N) < 0.03, sp, synth.double_decimal(N, patch_fraction=0)),
+        "pseudodecimal(bp,bp,dict(bp))")
     add("dbl_pseudo_nulls", synth.double_decimal(N), "pseudodecimal(bp,bp,uncompressed)", nullmap=synth.random_nullmap(N, 0.9))
     # a nullmap that is not one constant sends these trees through the generic kernels
     add("dbl_dict_nulls", synth.dictionary_values(N, 1020, dtype=np.float64), "dict(bp)", nullmap=synth.random_nullmap(N, 0.6, seed=3))

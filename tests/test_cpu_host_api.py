@@ -62,6 +62,36 @@ def test_plan_compiler_rejects_corrupt_headers():
         B.compress_chunk(np.zeros(4, np.int32), None, "rle(bp,bp,bp)")
 
 
+def test_plan_compiler_rejects_absurd_row_counts():
+    """A damaged tuple_count near 2^30 must not wrap the 32-bit table sizes of the plan: it is
+    refused before any table is placed."""
+    c = B.compress_chunk(synth.int_rle(4096), None, "rle(bp,bp)")
+    for rows in (2**30 - 1, 2**30 + 5, 2**32 - 1, 2**24 + 1):
+        bad = c.copy()
+        bad[8:12] = np.array([rows], dtype=np.uint32).view(np.uint8)
+        with pytest.raises(B.BtrError) as e:
+            B.describe(bad)
+        assert e.value.status in (2, 3)
+    c = B.compress_chunk(synth.int_for(4096), None, "pfor")
+    bad = c.copy()
+    bad[8:12] = np.array([2**30], dtype=np.uint32).view(np.uint8)
+    with pytest.raises(B.BtrError):
+        B.describe(bad)
+
+
+def test_part_inspect_matches_per_chunk_calls():
+    values = synth.int_for(200000)
+    image = B.compress_column(values, None, "for(bp)", threads=2)
+    infos, offsets, lengths = B.api.part_inspect(image)
+    assert len(infos) == 4
+    for i, (o, n) in enumerate(B.part_chunks(image)):
+        one = B.chunk_info(image[o:o + n])
+        assert (offsets[i], lengths[i]) == (o, n)
+        assert (infos[i].tuple_count, infos[i].scheme, infos[i].decoded_bytes) == (one.tuple_count, one.scheme, one.decoded_bytes)
+    with pytest.raises(B.BtrError):
+        B.api.part_inspect(image[:30])
+
+
 def test_column_part_image_layout():
     values = synth.int_for(200000)
     image = B.compress_column(values, None, "for(bp)", threads=2)

@@ -60,3 +60,54 @@ def test_shard_ranges_balance():
         assert all(r[i][1] == r[i + 1][0] for i in range(world - 1))
         per = [sum(sizes[a:b]) for a, b in r]
         assert max(per) - min(per) <= 2 * 262144
+
+
+def test_bench_relation_does_not_depend_on_the_rank_count(monkeypatch):
+    """bench.py shards ONE relation: the rows a rank generates for its block range are the rows
+    any other split of the same relation holds at those positions."""
+    sys.path.insert(0, ROOT)
+    import bench
+    monkeypatch.setattr(bench, "SEGMENT_BLOCKS", 3)
+    rows = 10 * 65536 + 777
+    names = ["rle", "pseudodecimal", "dict"]
+    whole = {n: bench.generate_range(n, rows, 0, 11, True) for n in names}
+    assert all(v.size == rows for v in whole.values())
+    for world in (2, 3, 4, 8):
+        ranges = [bench.rank_block_range(names, rows, r, world) for r in range(world)]
+        assert ranges[0][0] == 0 and ranges[-1][1] == 11
+        assert all(ranges[i][1] == ranges[i + 1][0] for i in range(world - 1))
+        for n in names:
+            got = np.concatenate([bench.generate_range(n, rows, b0, b1, True) for b0, b1 in ranges])
+            assert np.array_equal(got.view(np.uint8), whole[n].view(np.uint8)), (n, world)
+
+
+def test_bench_parent_spawns_one_process_per_rank(monkeypatch, capsys):
+    """`python bench.py --gpus N` outside torch.distributed.run: the parent starts N children with
+    RANK / LOCAL_RANK / WORLD_SIZE set, forwards rank 0's line and fails when a rank fails."""
+    sys.path.insert(0, ROOT)
+    import subprocess
+    import bench
+    started = []
+
+    class FakeProc:
+        def __init__(self, cmd, env=None, stdout=None):
+            self.rank = int(env["RANK"])
+            started.append((self.rank, env["LOCAL_RANK"], env["WORLD_SIZE"], env["MASTER_ADDR"], stdout))
+            self.returncode = 3 if (self.rank == 2 and fail) else 0
+
+        def communicate(self):
+            return (b'{"n_gpus": 4}\n', None)
+
+        def wait(self):
+            return self.returncode
+
+    monkeypatch.setattr(subprocess, "Popen", FakeProc)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4"])
+    args = bench.parse_args()
+    fail = False
+    assert bench.spawn_ranks(args) == 0
+    assert [s[0] for s in started] == [0, 1, 2, 3] and all(s[2] == "4" and s[3] == "127.0.0.1" for s in started)
+    assert started[0][4] == subprocess.PIPE and started[1][4] == subprocess.DEVNULL
+    assert '"n_gpus": 4' in capsys.readouterr().out
+    fail = True
+    assert bench.spawn_ranks(args) == 1

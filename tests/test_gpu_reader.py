@@ -122,27 +122,39 @@ def test_malformed_streams_are_reported_not_crashed(gpu_ctx):
     assert e.value.status == 2
 
 
-def test_full_size_column_properties(gpu_ctx):
-    """Full benchmark size (1 GiB raw, 4096 blocks): lossless against the generator, checked by a
-    64-bit checksum of checksums computed on the device, plus a sample of blocks against the oracle."""
+@pytest.mark.parametrize("gen,spec", [("int_for", "for(bp)"), ("int_rle", "rle(bp,bp)"), ("int_dict", "dict(bp)"),
+                                      ("double_decimal", "pseudodecimal(bp,bp,uncompressed)"),
+                                      ("int_outliers", "pfor")])
+def test_full_size_column_properties(gpu_ctx, gen, spec):
+    """Full benchmark size (268 435 456 rows, 4096 blocks): lossless against the generator, checked
+    by a checksum of per-block position-weighted checksums computed on the device (64-bit wrapping
+    arithmetic over the value bit patterns), plus a stride of blocks bit for bit against the oracle."""
     import torch
     rows = 268_435_456
-    values = synth.int_for(rows)
-    image = B.compress_column(values, None, "for(bp)")
+    values = getattr(synth, gen)(rows)
+    image = B.compress_column(values, None, spec)
     r = B.BtrReader(image, ctx=gpu_ctx)
     assert r.getChunkCount() == 4096
     out = r.decodeAll()
-    got = out[:rows * 4].view(torch.int32)
-    want = torch.from_numpy(values)
-    assert int(got.to(torch.int64).sum().item()) == int(values.astype(np.int64).sum())
-    per_block = got.view(4096, 65536).to(torch.int64)
+    wide = values.dtype == np.float64
+    got = out[:values.nbytes].view(torch.int64 if wide else torch.int32).view(4096, 65536)
     weights = torch.arange(1, 65537, dtype=torch.int64, device=got.device)
-    sums = (per_block * weights).sum(dim=1).cpu()
-    ref = (want.view(4096, 65536).to(torch.int64) * weights.cpu()).sum(dim=1)
-    assert torch.equal(sums, ref)
-    for i in (0, 1234, 4095):
+    sums = torch.empty(4096, dtype=torch.int64)
+    for lo in range(0, 4096, 512):  # in slices: the int64 products of a whole column would not fit beside it
+        sums[lo:lo + 512] = (got[lo:lo + 512].to(torch.int64) * weights).sum(dim=1).cpu()
+    bits = values.view(np.int64 if wide else np.int32).reshape(4096, 65536)
+    w = np.arange(1, 65537, dtype=np.int64)
+    ref = np.empty(4096, dtype=np.int64)
+    with np.errstate(over="ignore"):
+        for lo in range(0, 4096, 512):
+            ref[lo:lo + 512] = (bits[lo:lo + 512].astype(np.int64) * w).sum(axis=1)
+    assert np.array_equal(sums.numpy(), ref)
+    del got, out
+    for i in sorted(set(range(0, 4096, 409)) | {1234, 4095}):
         o, n = r.chunks[i]
-        np.testing.assert_array_equal(r.readColumn(i), pyoracle.decode_chunk(image[o:o + n]))
+        want = pyoracle.decode_chunk(image[o:o + n])
+        np.testing.assert_array_equal(_bits(r.readColumn(i)), _bits(want))
+        np.testing.assert_array_equal(_bits(want), _bits(values[i * 65536:(i + 1) * 65536]))
 
 
 @pytest.mark.gpu
@@ -155,6 +167,7 @@ def test_cpp_interface_round_trip(spec):
     r = subprocess.run([exe, "640000", spec], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "decompressed data matches original data" in r.stdout
+    assert "column part reader matches original data" in r.stdout
 
 
 @pytest.mark.gpu
