@@ -120,8 +120,35 @@ btrhost::Options to_options(const btr_compress_options* o) {
 
 }  // namespace
 
+// ---- the allocation-free entry point's device memory ---------------------------------------------
+// btr_gpu_decode_chunks_noalloc keeps everything a plan normally allocates (work items, launch
+// order, status words, programs, table slices) in one file-scope device array. Every GPU holds
+// its own copy at its own address: the address is taken once per device in btr_gpu_ctx_create
+// (hipGetSymbolAddress with that device current) and host code only ever uses that address.
+constexpr size_t kStaticBytes = 16u << 20;
+constexpr size_t kStaticMaxChunks = 256;
+constexpr size_t kStaticItemsOff = 0;                                          // WorkItem[256]
+constexpr size_t kStaticOrderOff = kStaticMaxChunks * sizeof(WorkItem);        // u32[256]
+constexpr size_t kStaticStatusOff = kStaticOrderOff + kStaticMaxChunks * 4;    // u32[256]
+constexpr size_t kStaticProgOff = 32u << 10;                                   // programs
+constexpr size_t kStaticTablesOff = 1u << 20;                                  // table slices
+static_assert(kStaticStatusOff + kStaticMaxChunks * 4 <= kStaticProgOff, "layout of the static area");
+static __device__ __align__(256) unsigned char g_static_scratch[kStaticBytes];
+
+namespace {
+struct StaticArea {
+  unsigned char* dev = nullptr;      // this device's copy of g_static_scratch
+  unsigned char* staging = nullptr;  // pinned host mirror of [0, kStaticTablesOff)
+  hipEvent_t uploaded = nullptr;     // the last call's upload has left the staging buffer
+};
+constexpr int kMaxDevices = 64;
+StaticArea g_static_area[kMaxDevices];
+std::mutex g_static_mutex;
+}  // namespace
+
 struct btr_gpu_ctx {
   int device;
+  StaticArea* area;
 };
 
 struct btr_gpu_plan {
@@ -659,7 +686,7 @@ btr_status btr_gpu_ctx_create(int device, btr_gpu_ctx** out) {
   hipError_t e = hipGetDeviceCount(&count);
   if (e != hipSuccess || count == 0)
     return fail(BTR_ERR_DEVICE, "no HIP device available: decoding requires an MI355X (gfx950) GPU");
-  if (device < 0 || device >= count ) return fail(BTR_ERR_INVALID_ARGUMENT, "device index out of range");
+  if (device < 0 || device >= count || device >= kMaxDevices) return fail(BTR_ERR_INVALID_ARGUMENT, "device index out of range");
   DeviceGuard guard(device);
   if (!guard.ok) return fail(BTR_ERR_DEVICE, "hipSetDevice failed");
   for (const void* k : kAllKernels) {
@@ -672,7 +699,29 @@ btr_status btr_gpu_ctx_create(int device, btr_gpu_ctx** out) {
   if (e != hipSuccess)
     return fail(BTR_ERR_DEVICE, std::string("decode kernel has no code object for this device (built for gfx950): ") +
                                     hipGetErrorString(e));
-  *out = new btr_gpu_ctx{device};
+  // Once per device, with that device current: the address of this GPU's copy of the static
+  // area, its pinned staging mirror and the event that guards the mirror.
+  StaticArea* area = &g_static_area[device];
+  {
+    std::lock_guard<std::mutex> lock(g_static_mutex);
+    if (!area->dev) {
+      unsigned char* ptr = nullptr;
+      if ((e = hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(g_static_scratch))) != hipSuccess || !ptr)
+        return hip_fail(e, "hipGetSymbolAddress(static scratch)");
+      unsigned char* staging = nullptr;
+      if ((e = hipHostMalloc((void**)&staging, kStaticTablesOff, hipHostMallocDefault)) != hipSuccess)
+        return hip_fail(e, "hipHostMalloc(staging)");
+      hipEvent_t ev = nullptr;
+      if ((e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) {
+        (void)hipHostFree(staging);
+        return hip_fail(e, "hipEventCreate");
+      }
+      area->staging = staging;
+      area->uploaded = ev;
+      area->dev = ptr;
+    }
+  }
+  *out = new btr_gpu_ctx{device, area};
   return BTR_OK;
 }
 
@@ -827,6 +876,75 @@ btr_status btr_gpu_decode(btr_gpu_ctx* ctx, btr_gpu_plan* plan, void* hip_stream
   HIP_TRY(launch(plan->main_kind, stream));
   for (uint32_t kind = 0; kind < KERNEL_KINDS; kind++)
     if (plan->side[kind]) HIP_TRY(hipStreamWaitEvent(stream, plan->side_done[kind], 0));
+  return BTR_OK;
+}
+
+btr_status btr_gpu_decode_chunks_noalloc(btr_gpu_ctx* ctx, const btr_chunk_desc* chunks, size_t n, void* hip_stream,
+                                         uint32_t* status_or) {
+  if (!ctx || (!chunks && n)) return fail(BTR_ERR_INVALID_ARGUMENT, "null argument");
+  if (status_or) *status_or = 0;
+  if (n == 0) return BTR_OK;
+  if (n > kStaticMaxChunks)
+    return fail(BTR_ERR_INVALID_ARGUMENT, "at most " + std::to_string(kStaticMaxChunks) + " chunks per allocation-free call");
+  StaticArea* area = ctx->area;
+  if (!area || !area->dev) return fail(BTR_ERR_DEVICE, "static decode area not initialised for this device");
+  DeviceGuard guard(ctx->device);
+  if (!guard.ok) return fail(BTR_ERR_DEVICE, "hipSetDevice failed");
+  std::vector<WorkItem> items;
+  std::vector<BuiltProgram> progs;
+  btr_plan_stats stats{};
+  Layout lo;
+  try {
+    const btr_status st = compile_chunks(chunks, n, items, progs, stats);
+    if (st != BTR_OK) return st;
+    lay_out(items, progs, stats, lo);
+  } catch (const std::bad_alloc&) {
+    return fail(BTR_ERR_OUT_OF_MEMORY, "out of host memory while compiling the plan");
+  }
+  if (kStaticProgOff + lo.blob.size() > kStaticTablesOff)
+    return fail(BTR_ERR_BUFFER_TOO_SMALL, "decode programs of these chunks exceed the static area (" +
+                                              std::to_string(kStaticTablesOff - kStaticProgOff) + " bytes)");
+  if (lo.scratch > kStaticBytes - kStaticTablesOff)
+    return fail(BTR_ERR_BUFFER_TOO_SMALL, "decode tables of these chunks exceed the static area (" +
+                                              std::to_string(kStaticBytes - kStaticTablesOff) + " bytes)");
+  unsigned char* const dev = area->dev;  // this GPU's copy of the static array
+  for (size_t i = 0; i < n; i++) {
+    items[i].scratch = progs[i].scratch_bytes ? (uint64_t)(uintptr_t)(dev + kStaticTablesOff) + items[i].scratch : 0;
+    items[i].debug_flags = 0;
+    items[i].debug_buf = 0;
+  }
+  hipStream_t stream = (hipStream_t)hip_stream;
+  // the previous call's upload must have left the pinned mirror before it is refilled
+  HIP_TRY(hipEventSynchronize(area->uploaded));
+  memcpy(area->staging + kStaticItemsOff, items.data(), n * sizeof(WorkItem));
+  memcpy(area->staging + kStaticOrderOff, lo.order.data(), n * 4);
+  memset(area->staging + kStaticStatusOff, 0, kStaticMaxChunks * 4);  // status words start at zero
+  memcpy(area->staging + kStaticProgOff, lo.blob.data(), lo.blob.size());
+  HIP_TRY(hipMemcpyAsync(dev, area->staging, kStaticProgOff + lo.blob.size(), hipMemcpyHostToDevice, stream));
+  HIP_TRY(hipEventRecord(area->uploaded, stream));
+  const WorkItem* d_items = reinterpret_cast<const WorkItem*>(dev + kStaticItemsOff);
+  const uint32_t* d_order = reinterpret_cast<const uint32_t*>(dev + kStaticOrderOff);
+  uint32_t* d_status = reinterpret_cast<uint32_t*>(dev + kStaticStatusOff);
+  const uint8_t* d_programs = dev + kStaticProgOff;
+  for (uint32_t kind = 0; kind < KERNEL_KINDS; kind++) {  // one launch per kernel kind, back to back on the stream
+    const size_t cnt = lo.kind_begin[kind + 1] - lo.kind_begin[kind];
+    if (!cnt) continue;
+    hipLaunchKernelGGL(kernel_of(kind), dim3((unsigned)cnt), dim3(threads_of(kind)), lo.kind_lds[kind], stream, d_items,
+                       d_order + lo.kind_begin[kind], d_programs, d_status);
+    HIP_TRY(hipGetLastError());
+  }
+  if (!status_or) return BTR_OK;
+  HIP_TRY(hipStreamSynchronize(stream));
+  uint32_t words[kStaticMaxChunks];
+  HIP_TRY(hipMemcpy(words, d_status, n * 4, hipMemcpyDeviceToHost));
+  uint32_t any = 0;
+  size_t first = n;
+  for (size_t i = 0; i < n; i++) {
+    if (words[i] && first == n) first = i;
+    any |= words[i];
+  }
+  *status_or = any;
+  if (any) return fail(BTR_ERR_CORRUPT, "malformed compressed stream in chunk " + std::to_string(first));
   return BTR_OK;
 }
 

@@ -176,6 +176,20 @@ const char* btr_kernel_name(uint32_t k);
  * BtrReader::readColumn (BtrReader.cpp:45-71) for all chunks at once. */
 btr_status btr_gpu_decode(btr_gpu_ctx* ctx, btr_gpu_plan* plan, void* hip_stream);
 
+/* btr_gpu_plan_create + btr_gpu_decode (+ btr_gpu_plan_check) in one call that allocates nothing:
+ * no hipMalloc / hipFree, no stream or event creation. It has no counterpart in the reference; it
+ * exists for callers that cannot allocate - tight serving loops and harnesses that forbid
+ * hipMalloc on the decode path. Inputs and outputs are the caller's device buffers, as in
+ * btr_gpu_plan_create. Everything a plan would allocate on the device (work items, programs,
+ * status words, tables that do not fit in LDS) lives in one 16 MiB static array per GPU, so a
+ * call takes at most 256 chunks whose programs fit in 992 KiB and whose spilled tables fit in
+ * 15 MiB (BTR_ERR_INVALID_ARGUMENT / BTR_ERR_BUFFER_TOO_SMALL beyond that). Every call on a GPU
+ * shares that GPU's array: calls that overlap on one GPU race (a call may start once the previous
+ * one's work on the stream has completed). With status_or == NULL the call only enqueues; otherwise
+ * it waits for the stream and returns BTR_ERR_CORRUPT when a kernel reported a malformed stream. */
+btr_status btr_gpu_decode_chunks_noalloc(btr_gpu_ctx* ctx, const btr_chunk_desc* chunks, size_t n, void* hip_stream,
+                                         uint32_t* status_or);
+
 /* Waits for the stream and reports malformed streams found by the kernels: *status_or is the OR
  * of all per-chunk status words (0 = clean), *first_bad the first chunk with a non-zero word.
  * Returns BTR_ERR_CORRUPT when any is set - the counterpart of the reference's
