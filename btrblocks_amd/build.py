@@ -36,7 +36,9 @@ def _sources():
     return out
 
 
-def build_library(force=False, verbose=False):
+def build_library(force=False, verbose=False, debug_steps=False):
+    """debug_steps: diagnostic build (-DBTR_DEBUG_STEPS) whose kernels honour the step-skipping
+    bits of BTR_DEBUG_FLAGS and record per-role wait times; never ship it."""
     srcs = _sources()
     if not force and _newer(LIB, srcs):
         return LIB
@@ -52,6 +54,8 @@ def build_library(force=False, verbose=False):
     ]
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
+    if debug_steps:
+        cmd.insert(1, "-DBTR_DEBUG_STEPS")
     subprocess.check_call(cmd)
     return LIB
 
@@ -87,7 +91,7 @@ def build_example(force=False):
 def main():
     force = "--force" in sys.argv
     verbose = "--verbose" in sys.argv
-    print(build_library(force, verbose))
+    print(build_library(force or "--debug-steps" in sys.argv, verbose, "--debug-steps" in sys.argv))
     print(build_oracle(force))
     print(build_example(force))
 

@@ -294,7 +294,7 @@ void lay_out(std::vector<WorkItem>& items, const std::vector<BuiltProgram>& prog
   lo.blob.assign(total, 0);
   size_t at = 0;
   for (size_t i = 0; i < items.size(); i++) {
-    items[i].pad = 0;
+    items[i].flags = 0;
     items[i].prog_off = (uint32_t)at;
     items[i].prog_bytes = (uint32_t)progs[i].program.size();
     memcpy(lo.blob.data() + at, progs[i].program.data(), progs[i].program.size());
@@ -346,6 +346,18 @@ btr_status finish_plan(btr_gpu_ctx* ctx, std::vector<WorkItem>& items, std::vect
     return st;
   };
   if (blob.size() > 0xFFFFFFF0ull) return cleanup(fail(BTR_ERR_UNSUPPORTED, "plan programs exceed 4 GiB"));
+  if (stats.launches > 1) {
+    // every kind but the one with the most chunks goes to a side stream
+    size_t most = 0;
+    uint32_t main_kind = 0;
+    for (uint32_t kind = 0; kind < KERNEL_KINDS; kind++)
+      if (lo.kind_begin[kind + 1] - lo.kind_begin[kind] > most) {
+        most = lo.kind_begin[kind + 1] - lo.kind_begin[kind];
+        main_kind = kind;
+      }
+    for (size_t i = 0; i < items.size(); i++)
+      if (progs[i].kernel != main_kind) items[i].flags |= ITEM_SIDE_LAUNCH;
+  }
   hipError_t e;
   if (scratch) {
     if ((e = hipMalloc((void**)&plan->d_scratch, scratch)) != hipSuccess)

@@ -120,6 +120,7 @@ struct Ctx {
   u32 table_base;                      // LDS byte offset of table space
   u32 red_off;                         // 64 bytes of LDS for block-wide reductions
   u32 consts_off;                      // LDS byte offset of the program's constant words
+  u32 side;                            // the item runs beside a plan's main launch (ITEM_SIDE_LAUNCH): raised wave priority
   u32 debug;                           // WorkItem::debug_flags
   u64 debug_buf;                       // WorkItem::debug_buf
 };
@@ -134,6 +135,13 @@ __device__ __forceinline__ const Seq& seq_at(const Ctx& c, u32 i) {
   return *reinterpret_cast<const Seq*>(lds_raw + c.seqs_off + i * sizeof(Seq));
 }
 __device__ __forceinline__ void raise(const Ctx& c, u32 bits) { atomicOr(c.status, bits); }
+// Back from a raised priority (header-chain walkers) to the work item's own.
+__device__ __forceinline__ void base_priority(const Ctx& c) {
+  if (c.side)
+    __builtin_amdgcn_s_setprio(2);
+  else
+    __builtin_amdgcn_s_setprio(0);
+}
 // Diagnostics: timestamp `slot` of this work item (constant 100 MHz clock), thread 0 only.
 #define BTR_STAMP(c, slot)                                                              \
   do {                                                                                  \
@@ -883,7 +891,7 @@ __device__ __forceinline__ void bp_index_wave(const Ctx& c, const Step& s) {
   __builtin_amdgcn_s_setprio(3);  // a serial chain other waves wait for
   walker_init(w, c, p, uniform(s.a[1]));
   walker_run(w);
-  __builtin_amdgcn_s_setprio(0);
+  base_priority(c);
   walker_finish(WalkEnd{w.W, w.rounded, w.groups, w.index_off, w.pos, w.g, w.bad, w.tail_word}, c, p);
 }
 
@@ -1192,7 +1200,6 @@ __device__ __forceinline__ void ring_wait(bool keep_one_batch) {
   else
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
-
 // Lane-constant selectors of the unpackers: lane l produces values l and l + 64 of a group, i.e.
 // position l % 32 of miniblocks l / 32 and l / 32 + 2.
 struct UnpackLane {
@@ -1346,32 +1353,80 @@ __device__ __forceinline__ void ring_walk_batch(u32 index_off, u32 jump_off, u32
 // found, [lo, hi) are the groups that start in batch t: their words are in the ring (a group that
 // starts in batch t may run into batch t+1, which has landed) and their index entries are written.
 // Ends with the walker's tail decode and a workgroup barrier.
-template <bool KEEP_PREVIOUS = false, u32 WAVES = kStreamWaves, typename Publish, typename Unpack>
+#ifdef BTR_DEBUG_STEPS
+// Diagnostic builds: time (100 MHz ticks) a wave spent in a section, summed over the batches of a
+// pass and stored as "item start + sum" so that the stamp report prints the sum.
+#define BTR_ACC_BEGIN() const u32 acc_t0_ = (u32)wall_clock64()
+#define BTR_ACC_END(acc) (acc) += (u32)wall_clock64() - acc_t0_
+#define BTR_ACC_STORE(c, slot, acc)                                                                       \
+  do {                                                                                                    \
+    if (((c).debug & 8) && (slot) && (threadIdx.x & 63) == 0 && (slot) < kDebugSlots)                     \
+      reinterpret_cast<u32*>((c).debug_buf)[slot] = reinterpret_cast<u32*>((c).debug_buf)[0] + (acc);     \
+  } while (0)
+#else
+#define BTR_ACC_BEGIN() do {} while (0)
+#define BTR_ACC_END(acc) do {} while (0)
+#define BTR_ACC_STORE(c, slot, acc) do {} while (0)
+#endif
+
+// EARLY_RELEASE (with KEEP_PREVIOUS): only the first unpack unit of iteration t may still read batch
+// t-1 (units lag the digits by less than one unit). The wave that takes that unit stores t + 1 into
+// the release word (ring_release_word) once its ring reads are done, and the loader refills the
+// slot of batch t-1 right then instead of at the next barrier: two batches in flight instead of one.
+// publish() values must then be unit counts boundaries such that "lo == hi" means "no unit".
+__device__ __forceinline__ u32 ring_release_word(const Ctx& c) { return c.red_off + 40; }
+
+template <bool KEEP_PREVIOUS = false, u32 WAVES = kStreamWaves, u32 DBG = 0, bool EARLY_RELEASE = false, typename Publish,
+          typename Unpack>
 __device__ __forceinline__ void ring_pass(const Ctx& c, const Pipe& p, const BpView& bp, u32 jump_off, Publish publish,
                                           Unpack unpack) {
+  static_assert(!EARLY_RELEASE || KEEP_PREVIOUS, "early release refines the keep-previous schedule");
+  u32 acc = 0;
+  (void)acc;
   const u32 lane = threadIdx.x & 63, wave = uniform(threadIdx.x >> 6);
   const u32 W = uniform(p.a[1]), groups = uniform(p.a[5]);
   const u32 batches = (W + kBatchWords - 1) / kBatchWords;
   const u32 slot_off = c.red_off + 32;  // two LDS words: published value after batch t, slot t & 1
   // KEEP_PREVIOUS: batch t-1 stays readable during iteration t (for unpackers that lag behind
   // the walker), at the price of one batch less in flight.
-  constexpr u32 ahead = KEEP_PREVIOUS ? kRingAhead - 1 : kRingAhead;
+  constexpr u32 ahead = KEEP_PREVIOUS && !EARLY_RELEASE ? kRingAhead - 1 : kRingAhead;
+  constexpr bool kTwoInFlight = !KEEP_PREVIOUS || EARLY_RELEASE;
 
   if (wave == WAVES - 1) {
     // ---- loader
     const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(bp.base, bp.bytes);
     for (u32 t = 0; t < ahead; t++) ring_issue<0>(rsrc, t, batches);
+    if (EARLY_RELEASE && lane == 0) lds_st32(ring_release_word(c), 0);
     // batches 0 and 1 landed (only batch 2 may still be in flight), then the start barrier
-    ring_wait(!KEEP_PREVIOUS && batches > 2);
+    ring_wait(kTwoInFlight && batches > 2);
     ring_mirror<0>();
     __builtin_amdgcn_s_barrier();
+    u32 prev_published = 0;
     for (u32 t = 0; t < batches; t++) {
       // before barrier t: batch t+1 landed; at most batch t+2 stays in flight
-      ring_wait(!KEEP_PREVIOUS && t + 2 < batches);
+      {
+        BTR_ACC_BEGIN();
+        ring_wait(kTwoInFlight && t + 2 < batches);
+        BTR_ACC_END(acc);
+      }
       if (((t + 1) & (kRingBatches - 1)) == 0) ring_mirror<0>();
-      __builtin_amdgcn_s_barrier();
-      ring_issue<0>(rsrc, t + ahead, batches);  // its slot held batch t + ahead - 4, fully consumed before this barrier
+      barrier_lds();
+      if (EARLY_RELEASE) {
+        // the slot of batch t + 3 holds batch t - 1: wait until this iteration's first unit (if there
+        // is one) has taken its words out of it
+        const u32 published = uniform(lds32(slot_off + 4 * (t & 1)));
+        if (t + ahead < batches && published != prev_published) {
+          // bounded: a release that never comes (it cannot) must not hang the GPU
+          for (u32 spin = 0; spin < (1u << 20); spin++) {
+            if (uniform(*reinterpret_cast<volatile const u32*>(lds_raw + ring_release_word(c))) == t + 1) break;
+            __builtin_amdgcn_s_sleep(2);
+          }
+        }
+        prev_published = published;
+      }
+      ring_issue<0>(rsrc, t + ahead, batches);  // its slot held batch t + ahead - 4, no longer read
     }
+    BTR_ACC_STORE(c, DBG == 9 ? 8 : DBG, acc);  // loader: waiting for its loads
   } else if (wave == 0) {
     // ---- walker: batch 0 before barrier 0, then batch t+1 during iteration t
     ChainState st{1, 0, 1};
@@ -1389,12 +1444,15 @@ __device__ __forceinline__ void ring_pass(const Ctx& c, const Pipe& p, const BpV
     for (u32 t = 0; t < batches; t++) {
       barrier_lds();
       if (t + 1 < batches) {
+        BTR_ACC_BEGIN();
         ring_walk_batch(bp.index_off, jump_off, t + 1, groups, st, bad_hdr);
         const u32 v = publish(st);
         if (lane == 0) lds_st32(slot_off + 4 * ((t + 1) & 1), v);
+        BTR_ACC_END(acc);
       }
     }
-    __builtin_amdgcn_s_setprio(0);
+    BTR_ACC_STORE(c, DBG == 9 ? 15 : DBG ? DBG + 1 : 0, acc);  // walker: walking and publishing
+    base_priority(c);
     // sentinel, flags and the VariableByte tail
     walker_finish(WalkEnd{W, bp.rounded, groups, bp.index_off, st.pos, st.g, __any(bad_hdr) ? 1u : 0u, tail_word}, c, p);
   } else {
@@ -1404,9 +1462,15 @@ __device__ __forceinline__ void ring_pass(const Ctx& c, const Pipe& p, const BpV
     for (u32 t = 0; t < batches; t++) {
       barrier_lds();
       const u32 hi = uniform(lds32(slot_off + 4 * (t & 1)));
+      BTR_ACC_BEGIN();
       unpack(lo, hi, wave - 1);
+      BTR_ACC_END(acc);
       lo = hi;
     }
+    if (DBG == 9)
+      BTR_ACC_STORE(c, 8 + wave, acc);  // every unpacker of the row pass: slots 9..14
+    else if (wave == 1)
+      BTR_ACC_STORE(c, DBG ? DBG + 2 : 0, acc);  // first unpacker: unpacking
   }
   __syncthreads();
 }
@@ -1529,40 +1593,80 @@ struct ExpCode {
   u32 codes;      // dictionary size, 0 for plain exponents
 };
 
-// Exception flags of the exponent stream: one ring pass whose unpackers turn every 64 rows into a
-// bitmap word (row i is set when its exponent is the exception code). Builds the stream-format
-// group index of the exponents on the way.
+// Lane-constant selectors when lane l owns rows 4l..4l+3 of a 256-row span, i.e. of two consecutive
+// 128-value groups of a bit-packed stream: group l / 32 of the span, miniblock (l / 8) % 4 of that
+// group, positions 4 * (l % 8).. of that miniblock.
+struct QuadLane {
+  u32 grp;  // which of the span's two groups
+  u32 sh;   // bit position of the miniblock's width byte in the group header
+  u32 pm;   // header bytes of the miniblocks in front of it
+  u32 k4;   // position of the lane's first value inside the miniblock
+};
+__device__ __forceinline__ QuadLane quad_lane() {
+  const u32 lane = threadIdx.x & 63, m = (lane >> 3) & 3;
+  QuadLane q;
+  q.grp = lane >> 5;
+  q.sh = 24 - 8 * m;
+  q.pm = m ? ~(0xFFFFFFFFu >> (8 * m)) : 0u;
+  q.k4 = 4 * (lane & 7);
+  return q;
+}
+// Whether every width byte of a group header is at most 8: four consecutive values then fit the
+// 32 bits one funnel shift delivers.
+__device__ __forceinline__ bool widths_le8(u32 hdr) {
+  return (hdr & 0xF0F0F0F0u) == 0 && ((hdr + 0x07070707u) & 0xF0F0F0F0u) == 0;
+}
+// At most 5: every value is below 32.
+__device__ __forceinline__ bool widths_le5(u32 hdr) { return ((hdr | (hdr + 0x02020202u)) & 0xF8F8F8F8u) == 0; }
+// Value k of a miniblock of width b (any width up to 32) out of two consecutive words.
+__device__ __forceinline__ u32 take_bits(u32 lo, u32 hi, u32 bit, u32 b) {
+  const u32 x = __builtin_amdgcn_alignbit(hi, lo, bit);
+  return __builtin_amdgcn_ubfe(x, 0u, b) | (x & (u32)__builtin_amdgcn_sbfe(b, 5, 1));
+}
+
+// Exception flags of the exponent stream: one ring pass whose unpackers mark every row whose
+// exponent is the exception code in the (cleared) bitmap. A wave takes 256 rows at a time, four
+// consecutive rows per lane: exponents are at most 5 bits wide, so one 8-byte LDS read and one
+// funnel shift fetch a lane's four values. Builds the stream-format group index of the exponents
+// on the way.
 __device__ __forceinline__ void stream_exception_bits(const Ctx& c, const Pipe& pe, const BpView& be, const RankView& rk,
                                                       u32 words, u32 n, u32 jump_off, const ExpCode& xc) {
-  const UnpackLane u = unpack_lane();
+  const QuadLane q = quad_lane();
   const u32 lane = threadIdx.x & 63;
-  ring_pass(
+  const u32 groups = uniform(pe.a[5]);
+  // groups indexed -> 256-row spans whose groups are both indexed (the last span of a stream with an
+  // odd number of groups has one)
+  auto spans = [&](u32 g) { return g >= groups ? (groups + 1) >> 1 : g >> 1; };
+  ring_pass<true, kStreamWaves, 6>(
       c, pe, be, jump_off, [](const ChainState& st) { return st.g; },
       [&](u32 g_lo, u32 g_hi, u32 uw) {
-        for (u32 G = g_lo + uw; G < g_hi; G += kUnpackWaves) {
-          const u64 ee = lds64(be.index_off + 8 * G);
-          const u32 first = uniform((u32)ee), hdr = uniform((u32)(ee >> 32));
-          // a half (two miniblocks) narrower than the exception value holds no patch row
-          const u32 w0 = hdr >> 24, w1 = (hdr >> 16) & 0xFF, w2 = (hdr >> 8) & 0xFF, w3 = hdr & 0xFF;
-          const bool small = (hdr & 0xE0E0E0E0u) == 0;  // all widths below 32
-          u64 m[2] = {0, 0};
-#pragma unroll
-          for (u32 h = 0; h < 2; h++) {
-            if ((h ? (w2 > w3 ? w2 : w3) : (w0 > w1 ? w0 : w1)) < xc.need_bits) continue;
-            const u32 b = __builtin_amdgcn_ubfe(hdr, h ? u.sh_hi : u.sh_lo, 8);
-            const u32 w = __builtin_amdgcn_sad_u8(hdr & (h ? u.pm_hi : u.pm_lo), 0u, first);
-            const u32 bit = __umul24(u.k, b);
+        for (u32 P = spans(g_lo) + uw; P < spans(g_hi); P += kUnpackWaves) {
+          const u32 G = 2 * P + q.grp;
+          const bool have = G < groups;
+          const u64 ee = lds64(be.index_off + 8 * (have ? G : 2 * P));
+          const u32 first = (u32)ee, hdr = (u32)(ee >> 32);
+          const u32 b = __builtin_amdgcn_ubfe(hdr, q.sh, 8);
+          // a span whose miniblocks are all narrower than the exception value holds no patch row
+          if (__builtin_amdgcn_ballot_w64(have && b >= xc.need_bits) == 0) continue;
+          const u32 w = __builtin_amdgcn_sad_u8(hdr & q.pm, 0u, first);
+          u32 f = 0;
+          if (__builtin_amdgcn_ballot_w64(!widths_le8(hdr)) == 0) {
+            const u32 bit = __umul24(q.k4, b);
             const u32x2 pair = ring_pair(((w + (bit >> 5)) << 2) & (kStreamRingBytes - 1));
-            const u32 xa = __builtin_amdgcn_alignbit(pair.y, pair.x, bit);
-            // width 32 (small is false then): the whole word
-            const u32 x = small ? __builtin_amdgcn_ubfe(xa, 0u, b)
-                                : (__builtin_amdgcn_ubfe(xa, 0u, b) | (xa & (u32)__builtin_amdgcn_sbfe(b, 5, 1)));
-            m[h] = __builtin_amdgcn_ballot_w64(x == xc.exception);
+            const u32 x = __builtin_amdgcn_alignbit(pair.y, pair.x, bit);
+#pragma unroll
+            for (u32 k = 0; k < 4; k++) f |= (__builtin_amdgcn_ubfe(x, k * b, b) == xc.exception ? 1u : 0u) << k;
+          } else {  // streams no compressor writes (exponents are below 32): one value at a time
+#pragma unroll
+            for (u32 k = 0; k < 4; k++) {
+              const u32 bit = __umul24(q.k4 + k, b);
+              const u32x2 pair = ring_pair(((w + (bit >> 5)) << 2) & (kStreamRingBytes - 1));
+              f |= (take_bits(pair.x, pair.y, bit, b) == xc.exception ? 1u : 0u) << k;
+            }
           }
-          if (lane == 0) {
-            if (2 * G < words) lds_st64(rk.bits_off + 16 * G, m[0]);
-            if (2 * G + 1 < words) lds_st64(rk.bits_off + 16 * G + 8, m[1]);
-          }
+          const u32 row = 256 * P + 4 * lane;  // a multiple of four: the flags stay inside one 32-bit word
+          if (have && f && (row >> 6) < words)
+            atomicOr(reinterpret_cast<u32*>(lds_raw + rk.bits_off + 4 * (row >> 5)), f << (row & 31));
         }
       });
   // rows of the VariableByte tail (decoded by the walker at the end of the pass)
@@ -1581,10 +1685,9 @@ __device__ __forceinline__ void stream_pseudo(const Ctx& c, const Pipe& root, co
   const Tab patches = resolve_tab(c, uniform(root.a[2]));
   const u32 n = uniform(root.count);
   const u32 words = n / 64 + 1;
-  const u32 groups_e = uniform(pe.a[5]);
   const __amdgpu_buffer_rsrc_t rsrc_d = make_rsrc(bd.base, bd.bytes), rsrc_e = make_rsrc(be.base, be.bytes);
   const __amdgpu_buffer_rsrc_t dst_rsrc = make_rsrc(dst, n * 8);
-  const UnpackLane u = unpack_lane();
+  const QuadLane q = quad_lane();
   u32 exbad = 0;
   u32 row_end = 0;  // rows the pass could produce (walker wave only; shared through LDS below)
 
@@ -1592,152 +1695,176 @@ __device__ __forceinline__ void stream_pseudo(const Ctx& c, const Pipe& root, co
   const u32 groups_d = uniform(pd.a[5]);
   // patch candidates are loaded through a descriptor: an index past the last patch reads 0
   const __amdgpu_buffer_rsrc_t rsrc_p = make_rsrc(patches.g, patches.count * 8);
-  // rows lag up to one exponent group behind the digits: their words may sit in the previous batch
-  ring_pass<true>(
+  // Digit number d out of the ring: its group's index entry gives the first payload word and the
+  // four widths.
+  auto ring_digit = [&](u32 d) -> u32 {
+    const u64 ed = lds64(bd.index_off + 8 * (d >> 7));
+    const u32 m = (d >> 5) & 3, hdr = (u32)(ed >> 32);
+    const u32 b = __builtin_amdgcn_ubfe(hdr, 24 - 8 * m, 8);
+    const u32 w = __builtin_amdgcn_sad_u8(hdr & ~(u32)(0xFFFFFFFFull >> (8 * m)), 0u, (u32)ed);
+    const u32 bit = __umul24(d & 31, b);
+    const u32x2 pair = ring_pair(((w + (bit >> 5)) << 2) & (kStreamRingBytes - 1));
+    return take_bits(pair.x, pair.y, bit, b);
+  };
+  // Exponent words and patch candidates of a wave's next span, in flight while the current span is
+  // produced: both come from global memory, and their latency would otherwise be paid once per span.
+  u32 pf_span = NONE, pf_eb = 0, pf_bit = 0, pf_word = 0, pf_xb = 0, pf_f = 0;
+  bool pf_narrow = false;
+  u32x2 pf_data;
+  u32x4 pf_patch;
+  pf_data.x = pf_data.y = 0;
+  pf_patch.x = pf_patch.y = pf_patch.z = pf_patch.w = 0;
+  const u32 spans_e = be.rounded >> 8;
+  // lane-constant masks: bits of a 64-bit bitmap word below the lane's first row, and where its four flags sit
+  const u32 below_lo = (4 * lane & 63) < 32 ? (1u << (4 * lane & 31)) - 1 : ~0u;
+  const u32 below_hi = (4 * lane & 63) < 32 ? 0u : (1u << (4 * lane & 31)) - 1;
+  auto exp_fetch = [&](u32 P) {
+    pf_span = P;
+    {
+      // exceptions in front of the lane's rows and among them; two patch candidates (one 16-byte
+      // load) cover a lane unless three of its four rows are patches
+      const u32 row = P < spans_e ? 256 * P + 4 * lane : 0;
+      const u32 w64 = row >> 6;
+      const u64 word = lds64(rk.bits_off + 8 * w64);
+      const u32 wl = (u32)word, wh = (u32)(word >> 32);
+      pf_xb = lds32(rk.rank_off + 4 * w64) + (u32)__builtin_popcount(wl & below_lo) + (u32)__builtin_popcount(wh & below_hi);
+      pf_f = __builtin_amdgcn_ubfe((lane & 8) ? wh : wl, 4 * lane & 31, 4);
+      pf_patch = __builtin_amdgcn_raw_buffer_load_b128(rsrc_p, pf_xb * 8, 0, 0);
+    }
+    const u64 ee = lds64(be.index_off + 8 * (P < spans_e ? 2 * P + q.grp : 0));
+    const u32 ef = (u32)ee, eh = (u32)(ee >> 32);
+    pf_eb = __builtin_amdgcn_ubfe(eh, q.sh, 8);
+    pf_word = __builtin_amdgcn_sad_u8(eh & q.pm, 0u, ef);
+    pf_narrow = __builtin_amdgcn_ballot_w64(!widths_le5(eh)) == 0;
+    pf_bit = __umul24(q.k4, pf_eb);
+    pf_data = __builtin_amdgcn_raw_buffer_load_b64(rsrc_e, (pf_word + (pf_bit >> 5)) * 4, 0, 0);
+  };
+  // rows lag up to one 256-row span behind the digits: their words may sit in the previous batch
+  u32 iteration = 0;  // batches this unpack wave has seen
+  ring_pass<true, kStreamWaves, 9, true>(
       c, pd, bd, jump_off,
       [&](const ChainState& st) {
-        // digits indexed so far -> rows that can be produced, in whole groups of the exponent stream
+        // digits indexed so far -> rows that can be produced, in whole 256-row spans
         const u32 digits_ready = st.g * btrfmt::FBP_GROUP < bd.rounded ? st.g * btrfmt::FBP_GROUP : bd.rounded;
         u32 r = select_clear(rk, words, n, digits_ready);
         r = r < be.rounded ? r : be.rounded;
-        r &= ~(btrfmt::FBP_GROUP - 1);
+        r &= ~255u;
         row_end = r;
         return r;
       },
       [&](u32 r_lo, u32 r_hi, u32 uw) {
-        // exponent groups [r_lo / 128, r_hi / 128), two per iteration, every lane four rows. A second
-        // group behind the end repeats the first one with dropped stores.
-        const u32 g_end = r_hi >> 7;
-        // The wave-uniform facts of an iteration's two groups are worked out in vector form (lane j
-        // for group j) and handed over by lane reads: far fewer scalar instructions than one
-        // dependent chain per group. The 128 rows of an exponent group use at most 128 consecutive
-        // digits, i.e. two digit groups, the first of them known from the rank in front of the
-        // group. Straight path: both digit groups packed with one width below 32 (the lane's digit
-        // then sits at a bit offset linear in its index) and all exponent widths <= 5 (a value is
-        // a table index as it is).
-        for (u32 G0 = (r_lo >> 7) + uw; G0 < g_end; G0 += 2 * kUnpackWaves) {
-          const bool have2 = G0 + kUnpackWaves < g_end;  // else the first group again, with dropped stores
-          u32 f_efirst, f_ehdr, f_digit, f_before, f_width;
+        // A wave takes a 256-row span (two groups of the exponent stream) per iteration, lane l rows
+        // 4l..4l+3: the four exponents come out of one 8-byte load and one funnel shift (they are at
+        // most 5 bits wide), one bitmap word and one rank entry give the exceptions in front of all
+        // four rows, the digit indexes of the rows follow from the first one, and the rows leave as
+        // two 16-byte stores.
+        // Span P belongs to unpack wave P % kUnpackWaves in every batch, so a wave knows its next span
+        // and loads that span's exponent words while it works on the current one: the global load
+        // latency would otherwise be paid once per batch, between two barriers.
+        iteration++;
+#ifdef BTR_DEBUG_STEPS
+        if (c.debug & 16) {  // diagnostic: loader, walker and barriers only
+          if (uw == 0 && lane == 0) lds_st32(ring_release_word(c), iteration);
+          return;
+        }
+#endif
+        u32 P = r_lo >> 8;
+        P += (uw + kUnpackWaves - P % kUnpackWaves) % kUnpackWaves;
+        for (; P < (r_hi >> 8); P += kUnpackWaves) {
+          const u32 R0 = 256 * P + 4 * lane;
+          if (pf_span != P) exp_fetch(P);  // first span of this wave
+          const u32 eb = pf_eb, ebit0 = pf_bit, ew = pf_word, xb = pf_xb, f = pf_f;
+          const bool narrow = pf_narrow;
+          const u32x2 ew2 = pf_data;
+          const u32x4 pt = pf_patch;
+          exp_fetch(P + kUnpackWaves);
+          u32 ex[4];
+          if (narrow) {
+            const u32 x = __builtin_amdgcn_alignbit(ew2.y, ew2.x, ebit0);
+#pragma unroll
+            for (u32 k = 0; k < 4; k++) ex[k] = __builtin_amdgcn_ubfe(x, k * eb, eb);
+          } else {  // streams no compressor writes: one exponent at a time
+#pragma unroll
+            for (u32 k = 0; k < 4; k++) {
+              const u32 ebit = __umul24(q.k4 + k, eb);
+              const u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(rsrc_e, (ew + (ebit >> 5)) * 4, 0, 0);
+              ex[k] = take_bits(t.x, t.y, ebit, eb);
+            }
+          }
+          u64 pw[4];
+          if (__builtin_amdgcn_ballot_w64(__builtin_popcount(f) > 2) == 0) {
+            const u64 p0 = ((u64)pt.y << 32) | pt.x, p1 = ((u64)pt.w << 32) | pt.z;
+            pw[0] = p0;
+            pw[1] = (f & 1) ? p1 : p0;
+            pw[2] = (f & 3) ? p1 : p0;
+            pw[3] = (f & 7) ? p1 : p0;
+          } else {  // a lane with three patches among its four rows: four single loads for the whole wave
+#pragma unroll
+            for (u32 k = 0; k < 4; k++) {
+              const u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(rsrc_p, (xb + (u32)__builtin_popcount(f & ((1u << k) - 1))) * 8, 0, 0);
+              pw[k] = ((u64)t.y << 32) | t.x;
+            }
+          }
+          // digits: row k takes digit number (row - exceptions before it). The span's digits are
+          // consecutive and lie in at most three groups of the digit stream, the first one known from
+          // the exceptions in front of the span. Straight path: those groups are packed with one
+          // width below 32, so digit d sits at bit (d - first digit of the first group) * width, plus
+          // one header word per group boundary crossed.
+          u32 dv[4];
           {
-            const u32 Gs = (lane & 1) && have2 ? G0 + kUnpackWaves : G0;
-            const u64 ee = lds64(be.index_off + 8 * Gs);
-            const u32 b0 = lds32(rk.rank_off + 8 * Gs), b1 = lds32(rk.rank_off + 8 * Gs + 4);
-            u32 gd = (Gs * btrfmt::FBP_GROUP - b0) >> 7;
-            gd = gd < groups_d ? gd : groups_d - 1;
-            const u64 q0 = lds64(bd.index_off + 8 * gd), q1 = lds64(bd.index_off + 8 * gd + 8);
-            const u32 eh = (u32)(ee >> 32), h0 = (u32)(q0 >> 32), h1 = (u32)(q1 >> 32), bw = h0 & 0xFF;
-            const bool st = (eh & 0xF8F8F8F8u) == 0 && ((eh + 0x02020202u) & 0xF8F8F8F8u) == 0 &&
-                            h0 == bw * 0x01010101u && (h1 == h0 || gd + 1 >= groups_d) && bw < 32;
-            f_efirst = (u32)ee;
-            f_ehdr = eh;
-            f_digit = (u32)q0 | ((Gs - gd) << 20);  // first payload word of the digit group (< 2^20) | groups ahead (< 2^10)
-            f_before = b0 | ((b1 - b0) << 24);      // exceptions before the group (<= 2^16) | in its first half (<= 64)
-            f_width = bw | (st ? 256u : 0u);
-          }
-          u32 Gc[2], e_first[2], e_hdr[2], before[2][2], d_word[2], d_bw[2], d_rel[2], out_base[2];
-          bool straight = true;
-          // Loads first, in the order their addresses become known, so that the latencies overlap:
-          // exponent words (global), exception bits -> patch candidates (global), then the digits.
-          u32x2 ew[2][2], pw[2][2];
-          u32 eb[2][2], ebit[2][2], in[2][2];
+            const u32 xb0 = uniform(lds32(rk.rank_off + 16 * P));
+            u32 g0 = (256 * P - xb0) >> 7;
+            g0 = g0 < groups_d ? g0 : groups_d - 1;
+            const u64 en = lds64(bd.index_off + 8 * (g0 + (lane < 3 ? lane : 0)));  // lanes 0..2: the three entries
+            const u32 h = (u32)(en >> 32);
+            const u32 h0 = __builtin_amdgcn_readlane(h, 0), h1 = __builtin_amdgcn_readlane(h, 1),
+                      h2 = __builtin_amdgcn_readlane(h, 2), first0 = __builtin_amdgcn_readlane((u32)en, 0);
+            const u32 bw = h0 & 0xFF;
+            const bool straight = h0 == bw * 0x01010101u && bw < 32 && (g0 + 1 >= groups_d || h1 == h0) &&
+                                  (g0 + 2 >= groups_d || h2 == h0);
+            u32 d = R0 - xb;
+            if (straight) {
+              u32 rel = d - 128 * g0;
 #pragma unroll
-          for (u32 j = 0; j < 2; j++) {
-            const bool have = j == 0 || have2;
-            Gc[j] = have ? G0 + j * kUnpackWaves : G0;
-            out_base[j] = have ? Gc[j] * (btrfmt::FBP_GROUP * 8) : 0x80000000u;  // out of range: dropped
-            e_first[j] = __builtin_amdgcn_readlane(f_efirst, j);
-            e_hdr[j] = __builtin_amdgcn_readlane(f_ehdr, j);
-            const u32 fd = __builtin_amdgcn_readlane(f_digit, j), fb = __builtin_amdgcn_readlane(f_before, j),
-                      fw = __builtin_amdgcn_readlane(f_width, j);
-            d_word[j] = fd & 0xFFFFF;
-            d_rel[j] = (fd >> 20) * btrfmt::FBP_GROUP;
-            before[j][0] = fb & 0xFFFFFF;
-            before[j][1] = before[j][0] + (fb >> 24);
-            d_bw[j] = fw & 0xFF;
-            straight = straight && (fw >> 8) != 0;
+              for (u32 k = 0; k < 4; k++) {
+                u32 pos;
+                asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(pos) : "v"(rel), "s"(bw), "v"((rel >> 7) << 5));
+                const u32x2 pair = ring_pair(((first0 + (pos >> 5)) << 2) & (kStreamRingBytes - 1));
+                dv[k] = __builtin_amdgcn_ubfe(__builtin_amdgcn_alignbit(pair.y, pair.x, pos), 0u, bw);
+                rel += 1 - ((f >> k) & 1);
+              }
+            } else {
 #pragma unroll
-            for (u32 h = 0; h < 2; h++) {
-              eb[j][h] = __builtin_amdgcn_ubfe(e_hdr[j], h ? u.sh_hi : u.sh_lo, 8);
-              const u32 w = __builtin_amdgcn_sad_u8(e_hdr[j] & (h ? u.pm_hi : u.pm_lo), 0u, e_first[j]);
-              ebit[j][h] = __umul24(u.k, eb[j][h]);
-              ew[j][h] = __builtin_amdgcn_raw_buffer_load_b64(rsrc_e, (w + (ebit[j][h] >> 5)) * 4, 0, 0);
+              for (u32 k = 0; k < 4; k++) {
+                dv[k] = ring_digit(d);  // beyond the last digit (patch rows only): any LDS word will do
+                d += 1 - ((f >> k) & 1);
+              }
             }
           }
-#pragma unroll
-          for (u32 j = 0; j < 2; j++) {
-            const u64 m0 = lds64(rk.bits_off + 16 * Gc[j]), m1 = lds64(rk.bits_off + 16 * Gc[j] + 8);
-            // exceptions in front of this lane's rows inside their 64-row halves
-            in[j][0] = __builtin_amdgcn_mbcnt_hi((u32)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((u32)m0, 0u));
-            in[j][1] = __builtin_amdgcn_mbcnt_hi((u32)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((u32)m1, 0u));
-#pragma unroll
-            for (u32 h = 0; h < 2; h++)
-              pw[j][h] = __builtin_amdgcn_raw_buffer_load_b64(rsrc_p, (before[j][h] + in[j][h]) * 8, 0, 0);
+          if (P == (r_lo >> 8)) {
+            // the first span of the iteration is the only one whose digits may sit in the previous
+            // batch: its words are in registers now, the loader may refill that slot
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane == 0) lds_st32(ring_release_word(c), iteration);
           }
-          auto rows = [&](auto tag) {
-            constexpr bool STRAIGHT = decltype(tag)::value;
-            u32 dlo[2][2], dhi[2][2], dbit[2][2], dwid[2][2], dfull[2][2];
+          u64 out[4];
 #pragma unroll
-            for (u32 j = 0; j < 2; j++)
-#pragma unroll
-              for (u32 h = 0; h < 2; h++) {
-                u32 a;
-                if (STRAIGHT) {
-                  const u32 rel = d_rel[j] + 64 * h - before[j][h] + lane - in[j][h];  // 0..255
-                  asm("v_mul_u32_u24_e32 %0, %1, %2" : "=v"(dbit[j][h]) : "s"(d_bw[j]), "v"(rel));
-                  a = ((d_word[j] + (dbit[j][h] >> 5) + (rel >> 7)) << 2) & (kStreamRingBytes - 1);
-                  dwid[j][h] = d_bw[j];
-                  dfull[j][h] = 0;
-                } else {
-                  const u32 di = Gc[j] * btrfmt::FBP_GROUP + 64 * h + lane - before[j][h] - in[j][h];
-                  const u64 ed = lds64(bd.index_off + 8 * (di >> 7));
-                  const u32 m = (di >> 5) & 3;
-                  const u32 hdr = (u32)(ed >> 32);
-                  dwid[j][h] = __builtin_amdgcn_ubfe(hdr, 24 - 8 * m, 8);
-                  const u32 w = __builtin_amdgcn_sad_u8(hdr & ~(0xFFFFFFFFu >> (8 * m)), 0u, (u32)ed);
-                  dbit[j][h] = __umul24(di & 31, dwid[j][h]);
-                  a = ((w + (dbit[j][h] >> 5)) << 2) & (kStreamRingBytes - 1);
-                  dfull[j][h] = (u32)__builtin_amdgcn_sbfe(dwid[j][h], 5, 1);  // all ones for width 32
-                }
-                const u32x2 pair = ring_pair(a);
-                dlo[j][h] = pair.x, dhi[j][h] = pair.y;
-              }
-            u32 xv[2][2];
-            u64 fr[2][2];
-#pragma unroll
-            for (u32 j = 0; j < 2; j++)
-#pragma unroll
-              for (u32 h = 0; h < 2; h++) {
-                const u32 xa = __builtin_amdgcn_alignbit(ew[j][h].y, ew[j][h].x, ebit[j][h]);
-                xv[j][h] = __builtin_amdgcn_ubfe(xa, 0u, eb[j][h]);
-                if (!STRAIGHT) xv[j][h] |= xa & (u32)__builtin_amdgcn_sbfe(eb[j][h], 5, 1);  // width 32
-                const u32 idx = STRAIGHT ? xv[j][h] : xv[j][h] & btrfmt::DEC_INDEX_MASK;
-                idx_max = idx_max > idx ? idx_max : idx;
-                // an exponent that is neither the exception code nor a table index: reported
-                if (!STRAIGHT && idx == (xc.exception & btrfmt::DEC_INDEX_MASK) && xv[j][h] != xc.exception) exbad |= 2;
-                fr[j][h] = lds64(frac_off + 8 * idx);
-              }
-#pragma unroll
-            for (u32 j = 0; j < 2; j++) {
-              u32x2 out[2];
-#pragma unroll
-              for (u32 h = 0; h < 2; h++) {
-                const u32 da = __builtin_amdgcn_alignbit(dhi[j][h], dlo[j][h], dbit[j][h]);
-                u32 dv = __builtin_amdgcn_ubfe(da, 0u, dwid[j][h]);
-                if (!STRAIGHT) dv |= da & dfull[j][h];
-                const u64 r = (u64)__double_as_longlong((double)(int)dv * __longlong_as_double((long long)fr[j][h]));
-                const bool patch = xv[j][h] == xc.exception;
-                out[h].x = patch ? pw[j][h].x : (u32)r;
-                out[h].y = patch ? pw[j][h].y : (u32)(r >> 32);
-              }
-              const u32 o = out_base[j] + lane * 8;
-              __builtin_amdgcn_raw_buffer_store_b64(out[0], dst_rsrc, o, 0, kStoreNt);
-              __builtin_amdgcn_raw_buffer_store_b64(out[1], dst_rsrc, o + 512, 0, kStoreNt);
-            }
-          };
-          if (straight)
-            rows(std::true_type{});
-          else
-            rows(std::false_type{});
+          for (u32 k = 0; k < 4; k++) {
+            // narrow exponent groups hold values below 32 only: table index as it is
+            const u32 idx = narrow ? ex[k] : ex[k] & btrfmt::DEC_INDEX_MASK;
+            idx_max = idx_max > ex[k] ? idx_max : ex[k];
+            const u64 fr = lds64(frac_off + 8 * idx);
+            const u64 r = (u64)__double_as_longlong((double)(int)dv[k] * __longlong_as_double((long long)fr));
+            out[k] = ex[k] == xc.exception ? pw[k] : r;
+          }
+          u32x4 s0, s1;
+          s0.x = (u32)out[0], s0.y = (u32)(out[0] >> 32), s0.z = (u32)out[1], s0.w = (u32)(out[1] >> 32);
+          s1.x = (u32)out[2], s1.y = (u32)(out[2] >> 32), s1.z = (u32)out[3], s1.w = (u32)(out[3] >> 32);
+#ifdef BTR_DEBUG_STEPS
+          if ((c.debug & 32) && s0.x != 0x12345678u) continue;  // diagnostic: no stores
+#endif
+          __builtin_amdgcn_raw_buffer_store_b128(s0, dst_rsrc, R0 * 8, 0, kStoreNt);
+          __builtin_amdgcn_raw_buffer_store_b128(s1, dst_rsrc, R0 * 8 + 16, 0, kStoreNt);
         }
       });
   // plain exponents: values above 23 are no table index; codes: values outside the dictionary
@@ -2800,6 +2927,8 @@ template <u32 THREADS, u32 BASE>
 __device__ __forceinline__ ProgramHeader load_program(const WorkItem& it, u32 item, const u8* __restrict__ programs,
                                                       u32* __restrict__ status, Ctx& c) {
   const u32 tid = threadIdx.x;
+  c.side = uniform(it.flags) & ITEM_SIDE_LAUNCH;
+  base_priority(c);  // raised for a few chunks beside a big launch
   {
     const u32* prog = reinterpret_cast<const u32*>(programs + it.prog_off);
     for (u32 o = tid; o < it.prog_bytes / 4; o += THREADS) lds_st32(BASE + 4 * o, prog[o]);
@@ -2912,7 +3041,8 @@ __device__ __forceinline__ void stream_pseudo_block(const WorkItem* __restrict__
   const Pipe& rp = pipe_at(c, uniform(root.a[0]));
   const Pipe& pd = pipe_at(c, uniform(rp.a[0]));
   const Pipe& pe = pipe_at(c, uniform(rp.a[1]));
-  const u32 frac_off = seq_lds(c, uniform(root.a[2])), jump_off = jump_scratch(c, root);
+  constexpr u32 frac_off = kStreamFracBase;
+  const u32 jump_off = jump_scratch(c, root);
   RankView rk;
   rk.bits_off = seq_lds(c, uniform(rp.a[3]));
   rk.rank_off = seq_lds(c, uniform(rp.a[4]));

@@ -129,11 +129,16 @@ struct WorkItem {
   uint32_t src_bytes;
   uint32_t debug_flags;  // diagnostics only (BTR_DEBUG_FLAGS): 8 = record step timestamps; in builds with
                          // -DBTR_DEBUG_STEPS also 1 = skip index walks, 2 = skip the root step,
-                         // 4 = root step only, k << 8 = stop before step k
-  uint32_t pad;
+                         // 4 = root step only, k << 8 = stop before step k; Pseudodecimal stream kernel:
+                         // 16 = loader, walker and barriers only, 32 = no stores; with 8 the stream kernels
+                         // also record how long each wave role was busy
+  uint32_t flags;        // ITEM_* bits
   uint64_t debug_buf;    // flag 8: kDebugSlots 100 MHz timestamps of this item
 };
 constexpr uint32_t kDebugSlots = 16;
+// The item belongs to a small launch that runs on a side stream beside the plan's main launch: its
+// waves raise their priority, or they would crawl among the main launch's waves and end long after it.
+enum : uint32_t { ITEM_SIDE_LAUNCH = 1u << 0 };
 
 // Device status bits, one word per work item.
 enum : uint32_t {
@@ -171,8 +176,11 @@ constexpr bool kernel_is_generic(uint32_t k) {
 constexpr uint32_t kBlockThreads = 256;
 constexpr uint32_t kStreamRingBytes = 16 * 1024;  // LDS ring of the streamed root step (4 batches of 1024 words)
 // The stream kernels keep the ring at LDS offset 0 (ring addresses are then a plain mask), one
-// mirror word behind it, and the program copy after that.
-constexpr uint32_t kStreamProgBase = kStreamRingBytes + 16;
+// mirror word behind it, then 32 doubles (the Pseudodecimal kernel's powers of ten by stream value:
+// at a fixed address, so that a lookup is one shift and a read with an immediate offset) and the
+// program copy after that.
+constexpr uint32_t kStreamFracBase = kStreamRingBytes + 16;
+constexpr uint32_t kStreamProgBase = kStreamFracBase + 32 * 8;
 // LDS scratch of one header-chain walker: a table of (1024 + 256) 16-bit jump pointers.
 constexpr uint32_t kWalkScratchBytes = (1024 + 256) * 2;
 // SIMDFastPFor page descriptor size and the LDS work area of S_PFOR_DECODE:

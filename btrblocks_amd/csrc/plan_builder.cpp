@@ -664,8 +664,7 @@ void build_program(const ColumnSource& src, BuiltProgram& out) {
       for (const Step& st : bld.steps)
         if (st.kind != S_BITMAP_EQ) keep.push_back(st);
       bld.steps = keep;
-      const uint32_t fractions = bld.add_seq(LOC_LDS, 0, DEC_INDEX_MASK + 1, 8, true);
-      bld.add_step(S_STREAM_ROOT, root, dst, fractions);
+      bld.add_step(S_STREAM_ROOT, root, dst);  // the powers-of-ten table sits at kStreamFracBase
       prog_base = kStreamProgBase;
       kernel = KERNEL_STREAM_PSEUDO;
     } else {
