@@ -2389,7 +2389,8 @@ __device__ __forceinline__ void pfor_decode(const Ctx& c, const Step& s) {
   const u32 work = seq_lds(c, uniform(s.a[5]));
   const u32 table_off = work, bytes_lds = work + 4096, tail_off = work + 8192, packed_lds = work + 9472,
             ebase_off = tail_off,  // 257 words; the tail stage is only used after the pages
-            jump_lds = packed_lds, pos_lds = packed_lds + 2 * (4096 + 512);  // dead before the rings fill
+            jump_lds = packed_lds, pos_lds = packed_lds + 2 * (4096 + 512),  // dead before the rings fill
+            exc_off = work + 25856, mask_off = exc_off + 4 * kPforExcCap, erank_off = mask_off + 32 * kPforSubBlocks;
   const u32 n = out.count;
   const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(base, W * 4);
   u32 bad = 0;
@@ -2532,9 +2533,108 @@ __device__ __forceinline__ void pfor_decode(const Ctx& c, const Step& s) {
     //    may run into piece p+1, which has landed); lane l extracts values l, l+64, l+128, l+192.
     //    Unpack and patches alternate over sub-ranges of the page's blocks: a 4-byte patch that
     //    arrives after its line has left the L2 costs a read-modify-write in memory.
-    constexpr u32 kSubBlocks = 64;
+    //    Exceptions are merged into the unpacked values before these are stored, so that every
+    //    output line is written once: a 4-byte patch that arrives after its line has left the L2
+    //    costs a read-modify-write in memory. Per sub-range of the page's blocks the exceptions'
+    //    high bits go to LDS in list order and every block gets a 256-bit mask of patched positions
+    //    (positions ascend inside a block, so the n-th set bit belongs to the block's n-th exception).
+    //    A sub-range with more exceptions than the LDS list holds, and a table in LDS, are patched in
+    //    place behind the unpack instead.
+    constexpr u32 kSubBlocks = kPforSubBlocks;
+    constexpr u32 kPatchUnroll = 4;  // exceptions per thread whose loads are in flight together
+    constexpr u32 kNowhere = 0xFFFFFFF0u;
+    const bool patch_global = out.loc != LOC_LDS;
+    const __amdgpu_buffer_rsrc_t patch_rsrc = make_rsrc(patch_global ? out.g : nullptr, patch_global ? out.count * 4 : 0);
+    // Where exception number en (of the page) lives: its block, position, and the two words that
+    // hold its packed high bits. Dead lanes, exceptions without stored bits (width 1) and
+    // out-of-range indexes point past the buffer descriptor (loads return 0, stores are dropped).
+    struct ExcRef {
+      u32 r, pos, lo_at, hi_at, sh, width;
+      bool live, counted;
+    };
+    auto locate = [&](u32 en_raw, u32 e_last) {
+      ExcRef x;
+      x.counted = en_raw < e_last;
+      bool live = x.counted;
+      const u32 en = live ? en_raw : 0u;
+      u32 r = 0;  // the last block whose first exception is at or before en
+#pragma unroll
+      for (u32 step = 128; step; step >>= 1) {
+        const u32 cand = r + step;
+        if (cand < blocks && lds32(ebase_off + 4 * (cand < blocks ? cand : 0u)) <= en) r = cand;
+      }
+      const u32 xi = en - lds32(ebase_off + 4 * r);
+      const u32 e = lds32(table_off + 16 * r), pos_off = lds32(table_off + 16 * r + 4), ex0 = lds32(table_off + 16 * r + 8);
+      const u32 b = e & 0xFF, k = e >> 16;
+      live = live && b < 32;
+      const u32 kc = k >= 2 ? k : 2u;
+      const u32 cls_word = lds32(d + 4 * (5 + kc - 2));
+      const u32 cls_size = k >= 2 ? lds32(d + 4 * (5 + 31 + kc - 2)) : 0u;
+      const u32 full = cls_size & ~127u;
+      x.pos = staged && pos_off + xi < bytes_off + bytes_size
+                  ? (u32)lds_raw[bytes_lds + skew + (pos_off - bytes_off) + xi]
+                  : __builtin_amdgcn_raw_buffer_load_b8(rsrc, pos_off + xi, 0, 0);  // past the payload: 0
+      const u32 q = ex0 + xi;
+      if (live && k >= 2 && q >= cls_size) bad = 1;
+      const bool stored_bits = live && k >= 2 && q < cls_size;
+      const bool simd = q < full;  // whole SIMD packs of 128 first, then plain packs of 32
+      const u32 qq = q - full;
+      const u32 bit = (simd ? (q & 127) >> 2 : qq & 31) * k;
+      const u32 w = simd ? cls_word + (q >> 7) * 4 * k + 4 * (bit >> 5) + (q & 3)
+                         : cls_word + (full >> 7) * 4 * k + (qq >> 5) * k + (bit >> 5);
+      x.lo_at = stored_bits ? w * 4 : kNowhere;
+      x.hi_at = stored_bits ? (w + (simd ? 4u : 1u)) * 4 : kNowhere;
+      x.sh = (bit & 31) | (b << 8) | ((live && k < 2 ? 1u : 0u) << 16);
+      x.width = stored_bits ? k : 0u;
+      x.r = r;
+      x.live = live;
+      return x;
+    };
+    auto high_bits = [](const ExcRef& x, u32 lo, u32 hi) {
+      const u32 a = __builtin_amdgcn_alignbit(hi, lo, x.sh & 31);
+      const u32 k = x.width;
+      const u32 v = (k >= 32 ? a : a & ((1u << k) - 1u)) | (x.sh >> 16);  // width 1: the bit is a one
+      return v << ((x.sh >> 8) & 31);
+    };
     for (u32 sb = 0; sb < blocks; sb += kSubBlocks) {
     const u32 se = sb + kSubBlocks < blocks ? sb + kSubBlocks : blocks;
+    const u32 e_first = uniform(lds32(ebase_off + 4 * sb)), e_last = se < blocks ? uniform(lds32(ebase_off + 4 * se)) : total_exc;
+    const bool merge = patch_global && e_last - e_first <= kPforExcCap;
+    if (merge) {
+      for (u32 w = tid; w < 8 * kSubBlocks; w += kBlockThreads) lds_st32(mask_off + 4 * w, 0);
+      __syncthreads();
+      for (u32 e0 = e_first; e0 < e_last; e0 += kBlockThreads * kPatchUnroll) {
+        ExcRef x[kPatchUnroll];
+        u32 lo[kPatchUnroll], hi[kPatchUnroll];
+#pragma unroll
+        for (u32 u = 0; u < kPatchUnroll; u++) x[u] = locate(e0 + u * kBlockThreads + tid, e_last);
+#pragma unroll
+        for (u32 u = 0; u < kPatchUnroll; u++) {
+          lo[u] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, x[u].lo_at, 0, 0);
+          hi[u] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, x[u].hi_at, 0, 0);
+        }
+#pragma unroll
+        for (u32 u = 0; u < kPatchUnroll; u++) {
+          if (!x[u].counted) continue;
+          // every listed exception gets its mask bit, so that ranks match list order
+          lds_st32(exc_off + 4 * (e0 + u * kBlockThreads + tid - e_first), x[u].live ? high_bits(x[u], lo[u], hi[u]) : 0u);
+          const u32 old = atomicOr(reinterpret_cast<u32*>(lds_raw + mask_off + 32 * (x[u].r - sb) + 4 * (x[u].pos >> 5)),
+                                   1u << (x[u].pos & 31));
+          if ((old >> (x[u].pos & 31)) & 1) bad = 1;  // two exceptions of a block at one position
+        }
+      }
+      __syncthreads();
+      if (tid < se - sb) {  // exceptions in front of each mask word, one byte each
+        u32 before = 0, packed_lo = 0, packed_hi = 0;
+#pragma unroll
+        for (u32 j = 0; j < 8; j++) {
+          (j < 4 ? packed_lo : packed_hi) |= (before & 0xFF) << (8 * (j & 3));
+          before += (u32)__builtin_popcount(lds32(mask_off + 32 * tid + 4 * j));
+        }
+        lds_st64(erank_off + 8 * tid, (u64)packed_lo | ((u64)packed_hi << 32));
+      }
+      __syncthreads();
+    }
     {
       const u32 lane = tid & 63, wave = uniform(tid >> 6);
       constexpr u32 kWaves = kBlockThreads / 64, kPiece = 256, kRing = 4 * kPiece;
@@ -2585,6 +2685,24 @@ __device__ __forceinline__ void pfor_decode(const Ctx& c, const Step& s) {
             v.y = __builtin_amdgcn_alignbit(hi.y, lo.y, bit) & mask;
             v.z = __builtin_amdgcn_alignbit(hi.z, lo.z, bit) & mask;
             v.w = __builtin_amdgcn_alignbit(hi.w, lo.w, bit) & mask;
+            if (merge) {
+              const u32 rb = r - sb;
+              const u32 mword = lds32(mask_off + 32 * rb + 4 * (lane >> 3));
+              const u32 nib = (mword >> (4 * (lane & 7))) & 15;
+              if (nib) {
+                u32 idx = uniform(lds32(ebase_off + 4 * r)) - e_first + lds_raw[erank_off + 8 * rb + (lane >> 3)] +
+                          (u32)__builtin_popcount(mword & ((1u << (4 * (lane & 7))) - 1u));
+                auto take = [&]() {
+                  const u32 h = lds32(exc_off + 4 * (idx < kPforExcCap ? idx : kPforExcCap - 1));
+                  idx++;
+                  return h;
+                };
+                if (nib & 1) v.x |= take();
+                if (nib & 2) v.y |= take();
+                if (nib & 4) v.z |= take();
+                if (nib & 8) v.w |= take();
+              }
+            }
             const u32 o = (first + r * btrfmt::PFOR_BLOCK + 4 * lane) * 4;
             if (to_global) {
               if (wide) {
@@ -2610,69 +2728,27 @@ __device__ __forceinline__ void pfor_decode(const Ctx& c, const Step& s) {
     }
     __syncthreads();  // also orders the stores above before the patches below
     BTR_STAMP(c, 11);
-    const u32 e_first = uniform(lds32(ebase_off + 4 * sb)), e_last = se < blocks ? uniform(lds32(ebase_off + 4 * se)) : total_exc;
-    // 4. exceptions, one thread each: exception e of the page belongs to the block r with
-    //    ebase[r] <= e < ebase[r + 1]; (value >> b) << b is ORed back in at its position
-    constexpr u32 kPatchUnroll = 4;  // exceptions per thread whose loads are in flight together
-    // Into global memory: no branch between a thread's loads, so the packed exception values and
-    // the low bits of all its exceptions are in flight together. Dead lanes, exceptions without
-    // stored bits (width 1) and out-of-range indexes read and write past their buffer
-    // descriptors (loads return 0, stores are dropped).
-    const bool patch_global = out.loc != LOC_LDS;
-    const __amdgpu_buffer_rsrc_t patch_rsrc = make_rsrc(patch_global ? out.g : nullptr, patch_global ? out.count * 4 : 0);
-    constexpr u32 kNowhere = 0xFFFFFFF0u;
-    for (u32 e0 = e_first; patch_global && e0 < e_last; e0 += kBlockThreads * kPatchUnroll) {
-      u32 at[kPatchUnroll], lo_at[kPatchUnroll], hi_at[kPatchUnroll], sh[kPatchUnroll], width[kPatchUnroll];
+    // 4. exceptions that were not merged, one thread each: exception e of the page belongs to the
+    //    block r with ebase[r] <= e < ebase[r + 1]; (value >> b) << b is ORed back in at its position.
+    //    Into global memory: no branch between a thread's loads, so the packed exception values and
+    //    the low bits of all its exceptions are in flight together.
+    for (u32 e0 = e_first; patch_global && !merge && e0 < e_last; e0 += kBlockThreads * kPatchUnroll) {
+      ExcRef x[kPatchUnroll];
+      u32 at[kPatchUnroll], lo[kPatchUnroll], hi[kPatchUnroll], old[kPatchUnroll];
 #pragma unroll
       for (u32 u = 0; u < kPatchUnroll; u++) {
-        const u32 en_raw = e0 + u * kBlockThreads + tid;
-        bool live = en_raw < e_last;
-        const u32 en = live ? en_raw : 0u;
-        u32 r = 0;  // the last block whose first exception is at or before en
-#pragma unroll
-        for (u32 step = 128; step; step >>= 1) {
-          const u32 cand = r + step;
-          if (cand < blocks && lds32(ebase_off + 4 * (cand < blocks ? cand : 0u)) <= en) r = cand;
-        }
-        const u32 x = en - lds32(ebase_off + 4 * r);
-        const u32 e = lds32(table_off + 16 * r), pos_off = lds32(table_off + 16 * r + 4), ex0 = lds32(table_off + 16 * r + 8);
-        const u32 b = e & 0xFF, k = e >> 16;
-        live = live && b < 32;
-        const u32 kc = k >= 2 ? k : 2u;
-        const u32 cls_word = lds32(d + 4 * (5 + kc - 2));
-        const u32 cls_size = k >= 2 ? lds32(d + 4 * (5 + 31 + kc - 2)) : 0u;
-        const u32 full = cls_size & ~127u;
-        const u32 pos = staged && pos_off + x < bytes_off + bytes_size
-                            ? (u32)lds_raw[bytes_lds + skew + (pos_off - bytes_off) + x]
-                            : __builtin_amdgcn_raw_buffer_load_b8(rsrc, pos_off + x, 0, 0);  // past the payload: 0
-        const u32 q = ex0 + x;
-        if (live && k >= 2 && q >= cls_size) bad = 1;
-        const bool stored_bits = live && k >= 2 && q < cls_size;
-        const bool simd = q < full;  // whole SIMD packs of 128 first, then plain packs of 32
-        const u32 qq = q - full;
-        const u32 bit = (simd ? (q & 127) >> 2 : qq & 31) * k;
-        const u32 w = simd ? cls_word + (q >> 7) * 4 * k + 4 * (bit >> 5) + (q & 3)
-                           : cls_word + (full >> 7) * 4 * k + (qq >> 5) * k + (bit >> 5);
-        lo_at[u] = stored_bits ? w * 4 : kNowhere;
-        hi_at[u] = stored_bits ? (w + (simd ? 4u : 1u)) * 4 : kNowhere;
-        sh[u] = (bit & 31) | (b << 8) | ((live && k < 2 ? 1u : 0u) << 16);
-        width[u] = stored_bits ? k : 0u;
-        at[u] = live ? (first + r * btrfmt::PFOR_BLOCK + pos) * 4 : kNowhere;
+        x[u] = locate(e0 + u * kBlockThreads + tid, e_last);
+        at[u] = x[u].live ? (first + x[u].r * btrfmt::PFOR_BLOCK + x[u].pos) * 4 : kNowhere;
       }
-      u32 lo[kPatchUnroll], hi[kPatchUnroll], old[kPatchUnroll];
 #pragma unroll
       for (u32 u = 0; u < kPatchUnroll; u++) {
-        lo[u] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, lo_at[u], 0, 0);
-        hi[u] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, hi_at[u], 0, 0);
+        lo[u] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, x[u].lo_at, 0, 0);
+        hi[u] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, x[u].hi_at, 0, 0);
         old[u] = __builtin_amdgcn_raw_buffer_load_b32(patch_rsrc, at[u], 0, 0);
       }
 #pragma unroll
-      for (u32 u = 0; u < kPatchUnroll; u++) {
-        const u32 x = __builtin_amdgcn_alignbit(hi[u], lo[u], sh[u] & 31);
-        const u32 k = width[u];
-        const u32 v = (k >= 32 ? x : x & ((1u << k) - 1u)) | (sh[u] >> 16);  // width 1: the bit is a one
-        __builtin_amdgcn_raw_buffer_store_b32(old[u] | (v << ((sh[u] >> 8) & 31)), patch_rsrc, at[u], 0, 0);
-      }
+      for (u32 u = 0; u < kPatchUnroll; u++)
+        __builtin_amdgcn_raw_buffer_store_b32(old[u] | high_bits(x[u], lo[u], hi[u]), patch_rsrc, at[u], 0, 0);
     }
     for (u32 e0 = e_first; !patch_global && e0 < e_last; e0 += kBlockThreads * kPatchUnroll) {
       u32 at[kPatchUnroll], hi_bits[kPatchUnroll], old[kPatchUnroll];

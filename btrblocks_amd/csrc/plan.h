@@ -190,8 +190,14 @@ constexpr uint32_t kWalkScratchBytes = (1024 + 256) * 2;
 //   [9472, 25856)      a 4 KiB ring of packed block data per wave of the generic kernels; before
 //                      the blocks are unpacked the same bytes hold the jump pointers of the
 //                      byte-container chain, u16[4096 + 512], and the record offset per block, u16[256]
+//   [25856, 27904)     high bits (value << b) of the exceptions of the current sub-range of blocks, in
+//                      exception order (kPforExcCap of them; a sub-range with more is patched in memory)
+//   [27904, 29952)     a 256-bit mask of exception positions per block of the sub-range
+//   [29952, 30464)     per block, the exceptions in front of each 32-bit word of its mask (8 bytes)
 constexpr uint32_t kPforPageWords = 5 + 31 + 31;
-constexpr uint32_t kPforWorkBytes = 25856;
+constexpr uint32_t kPforSubBlocks = 64;   // blocks unpacked between two exception preparations
+constexpr uint32_t kPforExcCap = 512;
+constexpr uint32_t kPforWorkBytes = 25856 + kPforExcCap * 4 + kPforSubBlocks * 32 + kPforSubBlocks * 8;
 // Streams with more groups than this get jump tables; shorter ones are walked without.
 constexpr uint32_t kWalkScratchMinGroups = 64;
 constexpr uint32_t kLdsCapBytes = 160 * 1024;  // all of a gfx950 CU's LDS; typical chunks need 5-40 KiB
