@@ -70,6 +70,43 @@ class ChunkDesc(C.Structure):
     ]
 
 
+class StringDictInfo(C.Structure):
+    _fields_ = [
+        ("tuple_count", C.c_uint32),
+        ("total_decompressed_size", C.c_uint32),
+        ("num_codes", C.c_uint32),
+        ("use_fsst", C.c_uint8),
+        ("use_rle_optimized_path", C.c_uint8),
+        ("codes_scheme", C.c_uint8),
+        ("lengths_scheme", C.c_uint8),
+        ("runs_count", C.c_uint32),
+        ("run_values_scheme", C.c_uint8),
+        ("run_lengths_scheme", C.c_uint8),
+        ("reserved", C.c_uint8 * 2),
+        ("pool_offset", C.c_uint32),
+        ("codes_offset", C.c_uint32),
+        ("lengths_offset", C.c_uint32),
+        ("fsst_offsets_offset", C.c_uint32),
+        ("run_values_offset", C.c_uint32),
+        ("run_lengths_offset", C.c_uint32),
+    ]
+
+
+SUBSTREAM_CODES, SUBSTREAM_LENGTHS, SUBSTREAM_RUN_VALUES, SUBSTREAM_RUN_LENGTHS = 0, 1, 2, 3
+
+
+class SubstreamDesc(C.Structure):
+    _fields_ = [
+        ("host_src", C.c_void_p),
+        ("dev_src", C.c_void_p),
+        ("src_bytes", C.c_size_t),
+        ("which", C.c_uint32),
+        ("reserved", C.c_uint32),
+        ("dev_dst", C.c_void_p),
+        ("dst_bytes", C.c_size_t),
+    ]
+
+
 class PlanStats(C.Structure):
     _fields_ = [
         ("chunks", C.c_uint64),
@@ -101,6 +138,11 @@ SIGNATURES = {
                                    C.POINTER(C.c_uint64)]),
     "btr_datablock_inspect": (C.c_int, [_P, C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "btr_datablock_column": (C.c_int, [_P, C.c_size_t, C.c_uint32, C.POINTER(ChunkInfo)]),
+    "btr_string_dict_inspect": (C.c_int, [_P, C.c_size_t, C.POINTER(StringDictInfo)]),
+    "btr_compress_string_dict_bound": (C.c_size_t, [C.c_uint64, C.c_uint32]),
+    "btr_compress_string_dict_chunk": (C.c_int, [_P, _P, C.c_uint32, _P, C.c_char_p, C.c_char_p, C.c_int,
+                                                 C.POINTER(CompressOptions), _P, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "btr_gpu_plan_create_string_dict": (C.c_int, [_P, C.POINTER(SubstreamDesc), C.c_size_t, C.POINTER(_P)]),
     "btr_compress_bound": (C.c_size_t, [C.c_uint8, C.c_uint32]),
     "btr_compress_chunk": (C.c_int, [C.c_uint8, _P, _P, C.c_uint32, C.c_char_p, C.POINTER(CompressOptions), _P,
                                      C.c_size_t, C.POINTER(C.c_size_t)]),

@@ -85,6 +85,15 @@ def part_chunks(part):
     return list(zip(offsets.tolist(), lengths.tolist()))
 
 
+def string_dict_info(chunk):
+    """Header fields of a string column chunk in the DICT scheme, offsets from the chunk start."""
+    lib = N.load()
+    a = _as_u8(chunk)
+    info = N.StringDictInfo()
+    N.check(lib.btr_string_dict_inspect(a.ctypes.data, a.size, C.byref(info)))
+    return info
+
+
 def datablock_columns(block):
     lib = N.load()
     a = _as_u8(block)
@@ -131,6 +140,31 @@ def compress_column(values, nullmap=None, scheme="auto", block_rows=65536, threa
     opt = _options(max_cascade_depth, enable_for)
     N.check(lib.btr_compress_column(ctype, values.ctypes.data, nm_ptr, n, block_rows, scheme.encode(),
                                     C.byref(opt), threads, out.ctypes.data, cap, C.byref(got)))
+    return out[:got.value].copy()
+
+
+def compress_string_dict_chunk(strings, nullmap=None, codes_scheme="auto", lengths_scheme="auto", fsst_layout=False):
+    """One block of a string column as a DICT chunk (strings::DynamicDictionary::compress).
+    `strings` is a sequence of bytes objects, or an (offsets[n + 1] uint32, bytes uint8) pair."""
+    lib = N.load()
+    if isinstance(strings, tuple):
+        offsets, text = strings
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint32)
+        text = np.ascontiguousarray(text, dtype=np.uint8)
+    else:
+        lens = np.fromiter((len(s) for s in strings), dtype=np.uint32, count=len(strings))
+        offsets = np.zeros(len(strings) + 1, dtype=np.uint32)
+        np.cumsum(lens, out=offsets[1:])
+        text = np.frombuffer(b"".join(strings), dtype=np.uint8)
+    n = offsets.size - 1
+    text = text if text.size else np.zeros(1, dtype=np.uint8)
+    nm, nm_ptr = _nullmap_ptr(nullmap, n)
+    cap = lib.btr_compress_string_dict_bound(int(offsets[-1]), n)
+    out = np.empty(cap, dtype=np.uint8)
+    got = C.c_size_t()
+    N.check(lib.btr_compress_string_dict_chunk(text.ctypes.data, offsets.ctypes.data, n, nm_ptr, codes_scheme.encode(),
+                                               lengths_scheme.encode(), 1 if fsst_layout else 0, None,
+                                               out.ctypes.data, cap, C.byref(got)))
     return out[:got.value].copy()
 
 
@@ -220,6 +254,18 @@ class DecodePlan:
         h = C.c_void_p()
         N.check(self.lib.btr_gpu_plan_create_part(ctx.handle, a.ctypes.data, dev_ptr, a.size, first, count, dst_ptr,
                                                   dst_bytes, nullmap_ptr, nullmap_bytes, C.byref(h)))
+        self.handle = h
+        return self
+
+    @classmethod
+    def for_string_dict(cls, ctx, descs, keepalive=()):
+        """Plan over integer sub-streams of string DICT chunks (btr_gpu_plan_create_string_dict);
+        `descs` is a list of _native.SubstreamDesc."""
+        self = cls.__new__(cls)
+        self.ctx, self.lib, self._keep = ctx, ctx.lib, keepalive
+        arr = (N.SubstreamDesc * len(descs))(*descs)
+        h = C.c_void_p()
+        N.check(self.lib.btr_gpu_plan_create_string_dict(ctx.handle, arr, len(descs), C.byref(h)))
         self.handle = h
         return self
 

@@ -14,6 +14,7 @@
 //   FrequencyStructure<T>      btrblocks/scheme/templated/Frequency.hpp:12-18
 //   DecimalStructure           btrblocks/scheme/double/Pseudodecimal.hpp:13-32
 //   FixedDictionaryStructure   btrblocks/scheme/templated/FixedDictionary.hpp:7-11
+//   string DICT structure      btrblocks/scheme/string/DynamicDictionary.hpp:7-18
 //   scheme codes               btrblocks/scheme/SchemeType.hpp:12-28, 35-47
 #pragma once
 #include <stdint.h>
@@ -59,6 +60,8 @@ enum : uint8_t {
   D_DICTIONARY_8 = 29,
   D_DICTIONARY_16 = 31,
 };
+// ---- string scheme wire codes (SchemeType.hpp:49-56); only DICT's integer sub-streams are decoded
+enum : uint8_t { S_UNCOMPRESSED = 0, S_ONE_VALUE = 1, S_DICT = 2, S_FSST = 3 };
 constexpr uint8_t SCHEME_AUTO = 255;  // autoScheme(), SchemeType.hpp:72-74
 
 // ---- chunk envelope: {u8 scheme, u8 nullmap_type, u8 column_type, pad, u32 nullmap_offset, u32 tuple_count}
@@ -84,6 +87,18 @@ constexpr uint32_t DEC_CONVERTED = 0, DEC_NUMBERS_SCHEME = 4, DEC_EXPONENTS_SCHE
                    DEC_PATCHES_SCHEME = 6, DEC_VARIANT = 7, DEC_EXPONENTS_OFFSET = 8,
                    DEC_PATCHES_OFFSET = 12, DEC_MAP_OFFSET = 16, DEC_DATA = 20;
 constexpr uint32_t FDICT_CODES_OFFSET = 0, FDICT_I_SLOTS = 4, FDICT_D_SLOTS = 8;
+// string DICT (not packed, so use_fsst is followed by 3 bytes of padding):
+// {u32 total_decompressed_size; bool use_fsst; u32 fsst_offsets_offset; u32 lengths_offset;
+// u32 num_codes; u32 codes_offset; bool use_rle_optimized_path; u8 codes_scheme;
+// u8 lengths_scheme; u8 data[]}; every *_offset counts from `data`.
+// Without FSST `data` starts with (num_codes + 1) u32 slots (offsets from `data`) and the
+// dictionary bytes; with FSST it starts with the exported symbol table (SDICT_FSST_HEADER bytes),
+// the compressed strings, (num_codes + 1) u32 offsets into them and the lengths stream.
+constexpr uint32_t SDICT_TOTAL_SIZE = 0, SDICT_USE_FSST = 4, SDICT_FSST_OFFSETS_OFFSET = 8,
+                   SDICT_LENGTHS_OFFSET = 12, SDICT_NUM_CODES = 16, SDICT_CODES_OFFSET = 20,
+                   SDICT_USE_RLE = 24, SDICT_CODES_SCHEME = 25, SDICT_LENGTHS_SCHEME = 26,
+                   SDICT_DATA = 27;
+constexpr uint32_t SDICT_FSST_HEADER = 8 + 1 + 8 + 2048 + 1;  // FSST_MAXHEADER of the fsst library
 
 // Pseudodecimal constants (btrblocks/scheme/double/Pseudodecimal.cpp:16-18)
 constexpr uint32_t DEC_MAX_EXPONENT = 22;

@@ -614,6 +614,37 @@ btr_status btr_compress_datablock(const btr_column_input* columns, uint32_t colu
   return BTR_OK;
 }
 
+size_t btr_compress_string_dict_bound(uint64_t string_bytes, uint32_t n) {
+  // pool (slots or symbol-table area + offsets + raw lengths) + raw codes + envelope, nullmap, padding
+  return 256 + SDICT_FSST_HEADER + (size_t)string_bytes + 3 * ((size_t)n + 1) * 4 + (size_t)n * 4 + 8;
+}
+
+btr_status btr_compress_string_dict_chunk(const uint8_t* bytes, const uint32_t* offsets, uint32_t n,
+                                          const uint8_t* nullmap, const char* codes_spec,
+                                          const char* lengths_spec, int fsst_layout,
+                                          const btr_compress_options* options, void* out, size_t cap,
+                                          size_t* out_bytes) {
+  if (!offsets || (!bytes && n && offsets[n] != offsets[0]) || !out || !out_bytes)
+    return fail(BTR_ERR_INVALID_ARGUMENT, "null argument");
+  btrhost::StringDictOptions sopt;
+  std::string err;
+  if (!btrhost::parse_spec(codes_spec, false, sopt.codes_spec, err)) return fail(BTR_ERR_INVALID_ARGUMENT, err);
+  if (!btrhost::parse_spec(lengths_spec, false, sopt.lengths_spec, err)) return fail(BTR_ERR_INVALID_ARGUMENT, err);
+  sopt.fsst_layout = fsst_layout != 0;
+  try {
+    std::vector<uint8_t> buf;
+    btrhost::compress_string_dict_chunk(bytes, offsets, n, nullmap, sopt, to_options(options), buf);
+    if (buf.size() > cap) return fail(BTR_ERR_BUFFER_TOO_SMALL, "output buffer too small");
+    memcpy(out, buf.data(), buf.size());
+    *out_bytes = buf.size();
+  } catch (const std::invalid_argument& e) {
+    return fail(BTR_ERR_INVALID_ARGUMENT, e.what());
+  } catch (const std::exception& e) {
+    return fail(BTR_ERR_UNSUPPORTED, e.what());
+  }
+  return BTR_OK;
+}
+
 size_t btr_compress_column_bound(uint8_t column_type, uint64_t rows, uint32_t block_rows) {
   if (block_rows == 0) block_rows = 65536;
   const uint64_t chunks = (rows + block_rows - 1) / block_rows;
@@ -815,6 +846,124 @@ btr_status btr_gpu_plan_create_datablock(btr_gpu_ctx* ctx, const void* host_bloc
     stats.tuples += n;
     stats.decoded_bytes += info.decoded_bytes;
     if (cs.want_nullmap) stats.nullmap_bytes += n;
+  }
+  stats.compile_seconds = now_s() - t0;
+  return finish_plan(ctx, items, progs, stats, out);
+}
+
+btr_status btr_string_dict_inspect(const void* chunk, size_t bytes, btr_string_dict_info* out) {
+  if (!chunk || !out) return fail(BTR_ERR_INVALID_ARGUMENT, "null argument");
+  const uint8_t* p = (const uint8_t*)chunk;
+  if (bytes < CHUNK_DATA) return fail(BTR_ERR_CORRUPT, "chunk shorter than its 12-byte envelope");
+  if (p[CHUNK_COL_TYPE] != COL_STRING || p[CHUNK_SCHEME] != S_DICT)
+    return fail(BTR_ERR_UNSUPPORTED, "not a string column chunk in the DICT scheme");
+  if (bytes > 0xFFFFFFFFull) return fail(BTR_ERR_UNSUPPORTED, "chunk above 4 GiB");
+  const size_t pool = (size_t)CHUNK_DATA + SDICT_DATA;
+  if (bytes < pool) return fail(BTR_ERR_CORRUPT, "chunk shorter than the string dictionary header");
+  const uint8_t* s = p + CHUNK_DATA;
+  memset(out, 0, sizeof(*out));
+  out->tuple_count = rd32(p + CHUNK_TUPLES);
+  out->total_decompressed_size = rd32(s + SDICT_TOTAL_SIZE);
+  out->num_codes = rd32(s + SDICT_NUM_CODES);
+  out->use_fsst = s[SDICT_USE_FSST] != 0;
+  out->use_rle_optimized_path = s[SDICT_USE_RLE] != 0;
+  out->codes_scheme = s[SDICT_CODES_SCHEME];
+  out->lengths_scheme = s[SDICT_LENGTHS_SCHEME];
+  out->pool_offset = (uint32_t)pool;
+  const size_t room = bytes - pool;
+  auto rebase = [&](uint32_t field, uint32_t* to, const char* what) -> btr_status {
+    const uint32_t off = rd32(s + field);
+    if (off > room) return fail(BTR_ERR_CORRUPT, std::string(what) + " offset past the end of the chunk");
+    *to = (uint32_t)(pool + off);
+    return BTR_OK;
+  };
+  btr_status st;
+  if ((st = rebase(SDICT_CODES_OFFSET, &out->codes_offset, "codes")) != BTR_OK) return st;
+  if (out->use_fsst) {
+    if ((st = rebase(SDICT_LENGTHS_OFFSET, &out->lengths_offset, "lengths")) != BTR_OK) return st;
+    if ((st = rebase(SDICT_FSST_OFFSETS_OFFSET, &out->fsst_offsets_offset, "string offsets")) != BTR_OK) return st;
+  }
+  if (out->num_codes > out->tuple_count) return fail(BTR_ERR_CORRUPT, "more dictionary entries than rows");
+  if (out->use_rle_optimized_path) {
+    if (out->codes_scheme != I_RLE) return fail(BTR_ERR_CORRUPT, "RLE-optimised path without an RLE codes stream");
+    const size_t node = out->codes_offset;
+    if (bytes - node < RLE_DATA) return fail(BTR_ERR_CORRUPT, "RLE header of the codes past the end of the chunk");
+    out->runs_count = rd32(p + node + RLE_RUNS);
+    const uint32_t counts_off = rd32(p + node + RLE_COUNTS_OFFSET);
+    if (out->runs_count > out->tuple_count) return fail(BTR_ERR_CORRUPT, "more runs than rows");
+    if (counts_off > bytes - node - RLE_DATA) return fail(BTR_ERR_CORRUPT, "run lengths past the end of the chunk");
+    out->run_values_scheme = p[node + RLE_VALUES_SCHEME];
+    out->run_lengths_scheme = p[node + RLE_COUNTS_SCHEME];
+    out->run_values_offset = (uint32_t)(node + RLE_DATA);
+    out->run_lengths_offset = (uint32_t)(node + RLE_DATA + counts_off);
+  }
+  return BTR_OK;
+}
+
+btr_status btr_gpu_plan_create_string_dict(btr_gpu_ctx* ctx, const btr_substream_desc* subs, size_t n,
+                                           btr_gpu_plan** out) {
+  if (!ctx || (!subs && n) || !out) return fail(BTR_ERR_INVALID_ARGUMENT, "null argument");
+  const double t0 = now_s();
+  std::vector<WorkItem> items(n);
+  std::vector<BuiltProgram> progs(n);
+  btr_plan_stats stats{};
+  for (size_t i = 0; i < n; i++) {
+    const btr_substream_desc& d = subs[i];
+    const std::string where = "item " + std::to_string(i) + ": ";
+    if (!d.host_src || !d.dev_src || !d.dev_dst) return fail(BTR_ERR_INVALID_ARGUMENT, where + "null pointer");
+    btr_string_dict_info info;
+    btr_status st = btr_string_dict_inspect(d.host_src, d.src_bytes, &info);
+    if (st != BTR_OK) return fail(st, where + g_error);
+    ColumnSource cs{};
+    cs.host = (const uint8_t*)d.host_src;
+    cs.bytes = d.src_bytes;
+    cs.dev_addr = (uint64_t)(uintptr_t)d.dev_src;
+    cs.column_type = COL_INTEGER;
+    cs.nullmap_type = NM_ALLONES;  // the sub-streams are compressed without a nullmap
+    cs.want_nullmap = false;
+    switch (d.which) {
+      case BTR_SUBSTREAM_CODES:
+        cs.payload_off = info.codes_offset;
+        cs.scheme = info.codes_scheme;
+        cs.tuple_count = info.tuple_count;
+        break;
+      case BTR_SUBSTREAM_LENGTHS:
+        if (!info.use_fsst) return fail(BTR_ERR_INVALID_ARGUMENT, where + "a chunk without FSST has no lengths stream");
+        cs.payload_off = info.lengths_offset;
+        cs.scheme = info.lengths_scheme;
+        cs.tuple_count = info.num_codes;
+        break;
+      case BTR_SUBSTREAM_RUN_VALUES:
+      case BTR_SUBSTREAM_RUN_LENGTHS:
+        if (!info.use_rle_optimized_path)
+          return fail(BTR_ERR_INVALID_ARGUMENT, where + "the chunk does not use the RLE-optimised path");
+        cs.payload_off = d.which == BTR_SUBSTREAM_RUN_VALUES ? info.run_values_offset : info.run_lengths_offset;
+        cs.scheme = d.which == BTR_SUBSTREAM_RUN_VALUES ? info.run_values_scheme : info.run_lengths_scheme;
+        cs.tuple_count = info.runs_count;
+        break;
+      default: return fail(BTR_ERR_INVALID_ARGUMENT, where + "unknown sub-stream");
+    }
+    if (d.dst_bytes < (uint64_t)cs.tuple_count * 4) return fail(BTR_ERR_BUFFER_TOO_SMALL, where + "destination too small");
+    if ((uint64_t)(uintptr_t)d.dev_dst % 8 != 0) return fail(BTR_ERR_MISALIGNED, where + "destination must be 8-byte aligned");
+    try {
+      build_program(cs, progs[i]);
+    } catch (const PlanError& e) {
+      return fail((btr_status)e.status, where + e.what());
+    } catch (const std::bad_alloc&) {
+      return fail(BTR_ERR_OUT_OF_MEMORY, "out of host memory while compiling the decode program");
+    } catch (const std::exception& e) {
+      return fail(BTR_ERR_CORRUPT, where + e.what());
+    }
+    WorkItem& it = items[i];
+    it.src = (uint64_t)(uintptr_t)d.dev_src;
+    it.dst = (uint64_t)(uintptr_t)d.dev_dst;
+    it.nullmap_dst = 0;
+    it.tuple_count = cs.tuple_count;
+    it.src_bytes = (uint32_t)d.src_bytes;
+    stats.tuples += cs.tuple_count;
+    stats.decoded_bytes += (uint64_t)cs.tuple_count * 4;
+    stats.stored_bytes += d.src_bytes;
+    stats.needed_bytes += CHUNK_DATA + SDICT_DATA;
   }
   stats.compile_seconds = now_s() - t0;
   return finish_plan(ctx, items, progs, stats, out);

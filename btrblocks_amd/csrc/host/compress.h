@@ -40,6 +40,23 @@ struct Options {
 size_t compress_chunk(uint8_t col_type, const void* values, const uint8_t* nullmap, uint32_t n,
                       const Spec& spec, const Options& opt, std::vector<uint8_t>& out);
 
+// String column chunk in the DICT scheme (btrblocks/scheme/string/DynamicDictionary.cpp:42-208):
+// sorted distinct strings, then the codes as an integer stream. `offsets` holds n + 1 byte
+// offsets into `bytes`. The codes are forced to RLE (use_rle_optimized_path) when the average run
+// is longer than 3 rows (:183-189); otherwise `codes_spec` applies. With `fsst_layout` the pool is
+// laid out as the FSST variant is (symbol-table area, string bytes, u32 offsets, lengths stream,
+// :89-152) but the strings are stored verbatim and the symbol-table area is zeroed: such a chunk
+// exercises the lengths sub-stream and is not readable by an FSST decoder.
+struct StringDictOptions {
+  Spec codes_spec;
+  Spec lengths_spec;
+  bool fsst_layout = false;
+  uint8_t codes_cascade_depth = 2;  // fsst_codes_max_cascade_depth, SchemeConfig.hpp:57
+};
+size_t compress_string_dict_chunk(const uint8_t* bytes, const uint32_t* offsets, uint32_t n,
+                                  const uint8_t* nullmap, const StringDictOptions& sopt,
+                                  const Options& opt, std::vector<uint8_t>& out);
+
 // Relation-level block (DatablockMeta + ColumnMeta[] + payloads), the format of
 // Datablock::compress(const Chunk&, BytesArray&) (btrblocks/compression/Datablock.cpp:192-338).
 struct ColumnInput {

@@ -70,6 +70,32 @@ btr_status btr_part_inspect(const void* part, size_t bytes, uint32_t first, uint
 btr_status btr_datablock_inspect(const void* block, size_t bytes, uint32_t* tuple_count, uint32_t* column_count);
 btr_status btr_datablock_column(const void* block, size_t bytes, uint32_t column, btr_chunk_info* out);
 
+/* String column chunk in the DICT scheme: the fields of DynamicDictionaryStructure
+ * (scheme/string/DynamicDictionary.hpp:7-18) with every offset rebased to the chunk start, plus the
+ * run count and child schemes of the codes' RLE node when use_rle_optimized_path is set
+ * (what RLE::decompressRuns reads, scheme/templated/RLE.hpp:111-128). Only the integer sub-streams
+ * of such a chunk are decoded by this library; the dictionary strings (FSST or plain) are not. */
+typedef struct btr_string_dict_info {
+  uint32_t tuple_count;
+  uint32_t total_decompressed_size;
+  uint32_t num_codes;              /* dictionary entries */
+  uint8_t use_fsst;
+  uint8_t use_rle_optimized_path;
+  uint8_t codes_scheme;            /* integer scheme code of the codes stream   */
+  uint8_t lengths_scheme;          /* integer scheme code of the lengths stream */
+  uint32_t runs_count;             /* RLE-optimised path only, else 0 */
+  uint8_t run_values_scheme;
+  uint8_t run_lengths_scheme;
+  uint8_t reserved[2];
+  uint32_t pool_offset;            /* DynamicDictionaryStructure::data */
+  uint32_t codes_offset;
+  uint32_t lengths_offset;         /* 0 without FSST */
+  uint32_t fsst_offsets_offset;    /* 0 without FSST */
+  uint32_t run_values_offset;      /* RLE-optimised path only, else 0 */
+  uint32_t run_lengths_offset;
+} btr_string_dict_info;
+btr_status btr_string_dict_inspect(const void* chunk, size_t bytes, btr_string_dict_info* out);
+
 /* ------------------------------------------------------------------------------------------
  * Compression (CPU). Stands in for Datablock::compress(const InputChunk&, u8*)
  * (compression/Datablock.cpp:66-148) and Datablock::compress(const Chunk&, BytesArray&)
@@ -106,6 +132,20 @@ btr_status btr_compress_column(uint8_t column_type, const void* values, const ui
                                const btr_compress_options* options, int threads, void* out,
                                size_t out_capacity, size_t* out_bytes);
 size_t btr_compress_column_bound(uint8_t column_type, uint64_t rows, uint32_t block_rows);
+
+/* One block of a string column as a DICT chunk (strings::DynamicDictionary::compress,
+ * scheme/string/DynamicDictionary.cpp:42-208). `offsets` holds tuple_count + 1 byte offsets into
+ * `bytes`. The codes are written as RLE with use_rle_optimized_path when the average run is
+ * longer than 3 rows (:183-189), otherwise as `codes_spec` says. The fsst library is not part of
+ * this build: with fsst_layout != 0 the pool is laid out as the FSST variant is (symbol-table area,
+ * string bytes, u32 offsets, lengths stream) but the strings are stored verbatim and the
+ * symbol-table area is zeroed, so such a chunk exercises the lengths sub-stream only. */
+size_t btr_compress_string_dict_bound(uint64_t string_bytes, uint32_t tuple_count);
+btr_status btr_compress_string_dict_chunk(const uint8_t* bytes, const uint32_t* offsets, uint32_t tuple_count,
+                                          const uint8_t* nullmap, const char* codes_spec,
+                                          const char* lengths_spec, int fsst_layout,
+                                          const btr_compress_options* options, void* out,
+                                          size_t out_capacity, size_t* out_bytes);
 
 /* ------------------------------------------------------------------------------------------
  * GPU decode.
@@ -149,6 +189,26 @@ btr_status btr_gpu_plan_create_part(btr_gpu_ctx* ctx, const void* host_part, con
 btr_status btr_gpu_plan_create_datablock(btr_gpu_ctx* ctx, const void* host_block, const void* dev_block,
                                          size_t bytes, void* const* dsts, uint8_t* const* nullmap_dsts,
                                          uint32_t column_count, btr_gpu_plan** out);
+
+/* Integer sub-streams of string DICT chunks, decoded with the integer kernels:
+ *   CODES       the code of every row:      codes_scheme.decompress(...), DynamicDictionary.cpp:381-387
+ *   LENGTHS     the length of every entry:  lengths_scheme.decompress(...), :444-451 (FSST chunks)
+ *   RUN_VALUES / RUN_LENGTHS  the (code, run length) pairs of the RLE-optimised path:
+ *               rle.decompressRuns(...), :239-251 and :484-496, templated/RLE.hpp:111-128
+ * Each item decodes one sub-stream of one chunk to int32 values at dev_dst (8-byte aligned; the
+ * counts are tuple_count, num_codes and runs_count of btr_string_dict_inspect). */
+enum { BTR_SUBSTREAM_CODES = 0, BTR_SUBSTREAM_LENGTHS = 1, BTR_SUBSTREAM_RUN_VALUES = 2, BTR_SUBSTREAM_RUN_LENGTHS = 3 };
+typedef struct btr_substream_desc {
+  const void* host_src;  /* the whole chunk, as in btr_chunk_desc */
+  const void* dev_src;
+  size_t src_bytes;
+  uint32_t which;        /* BTR_SUBSTREAM_* */
+  uint32_t reserved;
+  void* dev_dst;
+  size_t dst_bytes;
+} btr_substream_desc;
+btr_status btr_gpu_plan_create_string_dict(btr_gpu_ctx* ctx, const btr_substream_desc* items, size_t n,
+                                           btr_gpu_plan** out);
 void btr_gpu_plan_destroy(btr_gpu_plan* plan);
 
 typedef struct btr_plan_stats {

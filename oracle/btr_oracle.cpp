@@ -578,6 +578,83 @@ void decode_chunk(const u8* chunk, size_t bytes, void* dst, size_t dst_bytes, u8
   if (nullmap_dst) decode_nullmap(nullmap_dst, nm_type >= REGULAR ? data.from(nm_off) : data, nm_type, n);
 }
 
+// Integer sub-streams of a string column chunk in the DICT scheme. Header:
+// scheme/string/DynamicDictionary.hpp:7-18 (not packed: use_fsst is followed by 3 padding bytes,
+// data starts at byte 27; every *_offset counts from data).
+//   which 0  codes of all rows:        codes_scheme.decompress, DynamicDictionary.cpp:381-387
+//   which 1  lengths of all entries:   lengths_scheme.decompress, :444-451 (FSST chunks only)
+//   which 2  run values, which 3  run lengths of the RLE-optimised path:
+//            rle.decompressRuns, :239-251 / :484-496 and templated/RLE.hpp:111-128
+struct StringDict {
+  u32 n, total, num_codes;
+  bool use_fsst, use_rle;
+  u8 codes_scheme, lengths_scheme;
+  Span data;
+  Span codes, lengths;
+};
+StringDict open_string_dict(const u8* chunk, size_t bytes) {
+  const Span s{chunk, bytes, chunk};
+  if (s.b(2) != 2 || s.b(0) != 2) throw DecodeError("not a string column chunk in the DICT scheme");
+  StringDict d;
+  d.n = s.w(8);
+  const Span h = s.from(12);
+  d.total = h.w(0);
+  d.use_fsst = h.b(4) != 0;
+  d.num_codes = h.w(16);
+  d.use_rle = h.b(24) != 0;
+  d.codes_scheme = h.b(25);
+  d.lengths_scheme = h.b(26);
+  d.data = h.from(27);
+  d.codes = d.data.from(h.w(20));
+  d.lengths = d.use_fsst ? d.data.from(h.w(12)) : d.data;
+  return d;
+}
+void decode_string_dict_stream(const u8* chunk, size_t bytes, int which, std::vector<s32>& out) {
+  const StringDict d = open_string_dict(chunk, bytes);
+  const NullmapView none{false, 0};
+  if (which == 0) {
+    out.resize(d.n);
+    decode_int(out.data(), none, d.codes, d.n, d.codes_scheme, 1);
+  } else if (which == 1) {
+    if (!d.use_fsst) throw DecodeError("a chunk without FSST has no lengths stream");
+    if (d.num_codes > d.n) throw DecodeError("more dictionary entries than rows");
+    out.resize(d.num_codes);
+    decode_int(out.data(), none, d.lengths, d.num_codes, d.lengths_scheme, 1);
+  } else if (which == 2 || which == 3) {
+    if (!d.use_rle || d.codes_scheme != 3) throw DecodeError("the chunk does not use the RLE-optimised path");
+    const u32 runs = d.codes.w(0), counts_off = d.codes.w(4);
+    if (runs > d.n) throw DecodeError("RLE run count above tuple count");
+    const Span rle_data = d.codes.from(10);
+    out.resize(runs);
+    if (which == 2)
+      decode_int(out.data(), none, rle_data, runs, d.codes.b(8), 2);
+    else
+      decode_int(out.data(), none, rle_data.from(counts_off), runs, d.codes.b(9), 2);
+  } else {
+    throw DecodeError("unknown sub-stream");
+  }
+}
+
+// Rows of a DICT chunk without FSST: the copy loop of DynamicDictionary.cpp:405-416 over the
+// StringArrayViewer dictionary (slot i = offset of string i from the first slot).
+void decode_string_dict_rows(const u8* chunk, size_t bytes, std::vector<u32>& offsets, std::vector<u8>& text) {
+  const StringDict d = open_string_dict(chunk, bytes);
+  if (d.use_fsst) throw DecodeError("FSST dictionaries are not decoded");
+  std::vector<s32> codes(d.n);
+  decode_int(codes.data(), NullmapView{false, 0}, d.codes, d.n, d.codes_scheme, 1);
+  offsets.assign((size_t)d.n + 1, 0);
+  text.clear();
+  for (u32 i = 0; i < d.n; i++) {
+    if (codes[i] < 0 || (u32)codes[i] >= d.num_codes) throw DecodeError("dictionary code out of range");
+    const u32 a = d.data.w(4ull * codes[i]), b = d.data.w(4ull * codes[i] + 4);
+    if (b < a) throw DecodeError("dictionary slots decrease");
+    const u8* p = d.data.at(a, b - a);
+    offsets[i] = (u32)text.size();
+    text.insert(text.end(), p, p + (b - a));
+  }
+  offsets[d.n] = (u32)text.size();
+}
+
 }  // namespace
 
 extern "C" {
@@ -628,6 +705,44 @@ int btr_oracle_decode_datablock_column(const uint8_t* block, size_t bytes, uint3
       throw DecodeError("only integer and double columns are supported");
     }
     if (nullmap_dst) decode_nullmap(nullmap_dst, s.from(nm_type >= REGULAR ? nm_off : 0), nm_type, n);
+    return 0;
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    return -1;
+  }
+}
+
+// One integer sub-stream of a string DICT chunk (see decode_string_dict_stream). Writes at most
+// cap values; *count receives the length of the stream.
+int btr_oracle_string_dict_stream(const uint8_t* chunk, size_t bytes, int which, int32_t* out, size_t cap,
+                                  uint32_t* count) {
+  try {
+    std::vector<s32> v;
+    decode_string_dict_stream(chunk, bytes, which, v);
+    if (count) *count = (u32)v.size();
+    if (v.size() > cap) throw DecodeError("destination too small");
+    if (!v.empty()) memcpy(out, v.data(), v.size() * 4);
+    return 0;
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    return -1;
+  }
+}
+
+// Rows of a string DICT chunk without FSST: offsets[n + 1] into text. *text_bytes receives the
+// total length; text may be NULL to query it.
+int btr_oracle_string_dict_rows(const uint8_t* chunk, size_t bytes, uint32_t* offsets, size_t offsets_cap,
+                                uint8_t* text, size_t text_cap, uint64_t* text_bytes) {
+  try {
+    std::vector<u32> off;
+    std::vector<u8> txt;
+    decode_string_dict_rows(chunk, bytes, off, txt);
+    if (text_bytes) *text_bytes = txt.size();
+    if (text) {
+      if (off.size() > offsets_cap || txt.size() > text_cap) throw DecodeError("destination too small");
+      memcpy(offsets, off.data(), off.size() * 4);
+      if (!txt.empty()) memcpy(text, txt.data(), txt.size());
+    }
     return 0;
   } catch (const std::exception& e) {
     g_err = e.what();

@@ -39,6 +39,12 @@ def load():
         lib.btr_oracle_decompression_speed.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_size_t,
                                                        C.c_int, C.c_int, C.POINTER(C.c_uint64)]
         lib.btr_oracle_hardware_threads.restype = C.c_int
+        lib.btr_oracle_string_dict_stream.restype = C.c_int
+        lib.btr_oracle_string_dict_stream.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t,
+                                                      C.POINTER(C.c_uint32)]
+        lib.btr_oracle_string_dict_rows.restype = C.c_int
+        lib.btr_oracle_string_dict_rows.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p,
+                                                    C.c_size_t, C.POINTER(C.c_uint64)]
         _lib = lib
     return _lib
 
@@ -86,6 +92,40 @@ def decode_datablock(block):
             raise OracleError(lib.btr_oracle_error().decode())
         res.append((out, nm))
     return res
+
+
+CODES, LENGTHS, RUN_VALUES, RUN_LENGTHS = 0, 1, 2, 3
+
+
+def string_dict_stream(chunk, which):
+    """One integer sub-stream (CODES / LENGTHS / RUN_VALUES / RUN_LENGTHS) of a string DICT chunk."""
+    lib = load()
+    a = _u8(chunk)
+    count = C.c_uint32()
+    n = int(a[8:12].view(np.uint32)[0]) if a.size >= 12 else 0
+    out = np.empty(max(n, 1), dtype=np.int32)
+    rc = lib.btr_oracle_string_dict_stream(a.ctypes.data, a.size, which, out.ctypes.data, out.size, C.byref(count))
+    if rc != 0:
+        raise OracleError(lib.btr_oracle_error().decode())
+    return out[:count.value].copy()
+
+
+def string_dict_rows(chunk):
+    """(offsets[n + 1], bytes) of the rows of a string DICT chunk without FSST."""
+    lib = load()
+    a = _u8(chunk)
+    total = C.c_uint64()
+    rc = lib.btr_oracle_string_dict_rows(a.ctypes.data, a.size, None, 0, None, 0, C.byref(total))
+    if rc != 0:
+        raise OracleError(lib.btr_oracle_error().decode())
+    n = int(a[8:12].view(np.uint32)[0])
+    offsets = np.empty(n + 1, dtype=np.uint32)
+    text = np.empty(max(total.value, 1), dtype=np.uint8)
+    rc = lib.btr_oracle_string_dict_rows(a.ctypes.data, a.size, offsets.ctypes.data, offsets.size, text.ctypes.data,
+                                         text.size, C.byref(total))
+    if rc != 0:
+        raise OracleError(lib.btr_oracle_error().decode())
+    return offsets, text[:total.value].copy()
 
 
 def decompression_speed(image, chunks, threads=0, reps=1):
