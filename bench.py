@@ -153,6 +153,89 @@ def cpu_baseline(cols, sample_chunks, budget_s=12.0):
     }
 
 
+def pipeline_rate(ctx, cols, passes=2, slots=3):
+    """Host-to-host rate of the same columns through the part pipeline (btr_gpu_pipeline): the
+    compressed columns start as 16 MiB column parts in pinned host memory (a warm page cache), the
+    decoded columns end in pinned host memory. Every pass walks the headers and compiles the decode
+    programs again, copies the parts in, decodes and copies the columns out, overlapped over parts."""
+    import btrblocks_amd as B
+    from btrblocks_amd import api, files
+    part_views, out_need, total_in = [], 0, 0
+    layouts = []
+    for c in cols:
+        image = c["image"]
+        groups, cur, cur_bytes = [], [], 0
+        for off, n in B.part_chunks(image):
+            if cur and cur_bytes + n > files.PART_BYTES:
+                groups.append(cur)
+                cur, cur_bytes = [], 0
+            cur.append((off, n))
+            cur_bytes += n
+        if cur:
+            groups.append(cur)
+        col_parts = []
+        for g in groups:
+            at = 4 + 4 * len(g)
+            places = []
+            for off, n in g:
+                at = (at + 15) // 16 * 16
+                places.append(at)
+                at += n
+            col_parts.append((g, places, at))
+            total_in += (at + 255) // 256 * 256
+        layouts.append(col_parts)
+    pinned_in = api.PinnedBuffer(total_in + 256)
+    at = 0
+    jobs = []  # (part view, decoded bytes)
+    for c, col_parts in zip(cols, layouts):
+        image = c["image"]
+        elem = 8 if image[B.part_chunks(image)[0][0] + 2] == 1 else 4
+        col_out = 0
+        for g, places, nbytes in col_parts:
+            view = pinned_in.array[at:at + nbytes]
+            view[:4 + 4 * len(g)] = np.array([len(g)] + places, dtype=np.uint32).view(np.uint8)
+            decoded = 0
+            for (off, n), place in zip(g, places):
+                view[place:place + n] = image[off:off + n]
+                tuples = int(image[off + 8:off + 12].view(np.uint32)[0])
+                decoded = (decoded + 15) // 16 * 16 + tuples * elem
+            jobs.append((view, decoded, col_out))
+            col_out = (col_out + decoded + 15) // 16 * 16
+            at += (nbytes + 255) // 256 * 256
+        out_need = max(out_need, col_out)
+    pinned_out = api.PinnedBuffer(out_need + 256)
+    pipe = api.PartPipeline(ctx, slots)
+    total_out = sum(d for _, d, _ in jobs)
+
+    def one_pass():
+        for view, decoded, col_out in jobs:
+            pipe.submit(view, host_dst=pinned_out.ptr + col_out, dst_bytes=decoded)
+        pipe.drain()
+
+    one_pass()  # grows the pipeline's buffers
+    before = pipe.stats
+    c0, w0 = before.compile_seconds, before.wait_seconds
+    t0 = time.perf_counter()
+    for _ in range(passes):
+        one_pass()
+    dt = (time.perf_counter() - t0) / passes
+    after = pipe.stats
+    res = {
+        "what": "pinned host column parts -> plan compile -> H2D -> decode -> D2H -> pinned host columns, overlapped over parts",
+        "out_GBps": round(total_out / dt / 1e9, 2),
+        "in_GBps": round(sum(v.size for v, _, _ in jobs) / dt / 1e9, 2),
+        "ms_per_pass": round(dt * 1e3, 2),
+        "parts": len(jobs),
+        "slots": slots,
+        "compile_s_per_pass": round((after.compile_seconds - c0) / passes, 4),
+        "slot_wait_s_per_pass": round((after.wait_seconds - w0) / passes, 4),
+    }
+    pipe.close()
+    pinned_in.close()
+    pinned_out.close()
+    return res
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -165,6 +248,7 @@ def parse_args():
     ap.add_argument("--relation", action="store_true", help="N = 1: decode the mixed relation of the N > 1 runs")
     ap.add_argument("--cpu-sample-chunks", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pipeline", action="store_true", help="skip the host-to-host leg through the part pipeline")
     ap.add_argument("--nulls", type=float, default=None, metavar="P",
                     help="give every column a random nullmap with a fraction P of valid rows and decode the byte-per-row maps too")
     ap.add_argument("--no-verify", action="store_true", help="skip the oracle check of a sample of blocks after the timed region")
@@ -412,6 +496,8 @@ def run_rank(args):
                 "threads": host_threads,
             },
         }
+        if world == 1 and not args.no_pipeline:
+            line["host"]["pipeline"] = pipeline_rate(ctx, cols)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cols, args.cpu_sample_chunks)
         print(json.dumps(line), flush=True)

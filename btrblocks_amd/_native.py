@@ -125,6 +125,31 @@ class PlanStats(C.Structure):
     ]
 
 
+class PartJob(C.Structure):
+    _fields_ = [
+        ("host_part", C.c_void_p),
+        ("bytes", C.c_size_t),
+        ("host_dst", C.c_void_p),
+        ("dev_dst", C.c_void_p),
+        ("dst_bytes", C.c_size_t),
+        ("host_nullmap_dst", C.c_void_p),
+        ("dev_nullmap_dst", C.c_void_p),
+        ("nullmap_bytes", C.c_size_t),
+    ]
+
+
+class PipelineStats(C.Structure):
+    _fields_ = [
+        ("parts", C.c_uint64),
+        ("chunks", C.c_uint64),
+        ("tuples", C.c_uint64),
+        ("stored_bytes", C.c_uint64),
+        ("decoded_bytes", C.c_uint64),
+        ("compile_seconds", C.c_double),
+        ("wait_seconds", C.c_double),
+    ]
+
+
 # Every symbol include/btrblocks_amd.h declares: name -> (restype, argtypes)
 _P = C.c_void_p
 SIGNATURES = {
@@ -166,6 +191,14 @@ SIGNATURES = {
     "btr_gpu_decode_chunks_noalloc": (C.c_int, [_P, C.POINTER(ChunkDesc), C.c_size_t, _P, C.POINTER(C.c_uint32)]),
     "btr_gpu_plan_check": (C.c_int, [_P, _P, _P, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]),
     "btr_gpu_decode_chunk_host": (C.c_int, [_P, _P, C.c_size_t, _P, C.c_size_t, _P]),
+    "btr_gpu_pipeline_create": (C.c_int, [_P, C.c_uint32, C.POINTER(_P)]),
+    "btr_gpu_pipeline_destroy": (None, [_P]),
+    "btr_gpu_pipeline_acquire": (C.c_int, [_P, C.c_size_t, C.POINTER(_P)]),
+    "btr_gpu_pipeline_submit": (C.c_int, [_P, C.POINTER(PartJob)]),
+    "btr_gpu_pipeline_drain": (C.c_int, [_P, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]),
+    "btr_gpu_pipeline_stats": (C.c_int, [_P, C.POINTER(PipelineStats)]),
+    "btr_host_alloc": (C.c_int, [C.c_size_t, C.POINTER(_P)]),
+    "btr_host_free": (C.c_int, [_P]),
     "btr_gpu_malloc": (C.c_int, [_P, C.c_size_t, C.POINTER(_P)]),
     "btr_gpu_free": (C.c_int, [_P, _P]),
     "btr_gpu_upload": (C.c_int, [_P, _P, _P, C.c_size_t]),

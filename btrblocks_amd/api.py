@@ -306,6 +306,74 @@ class DecodePlan:
         self.close()
 
 
+class PinnedBuffer:
+    """Pinned host memory (btr_host_alloc) seen as a uint8 numpy array."""
+
+    def __init__(self, nbytes):
+        self.lib = N.load()
+        p = C.c_void_p()
+        N.check(self.lib.btr_host_alloc(max(int(nbytes), 1), C.byref(p)))
+        self.ptr = p.value
+        self.nbytes = int(nbytes)
+        self.array = np.ctypeslib.as_array((C.c_uint8 * max(self.nbytes, 1)).from_address(self.ptr))[:self.nbytes]
+
+    def close(self):
+        if getattr(self, "ptr", None):
+            self.array = None
+            self.lib.btr_host_free(C.c_void_p(self.ptr))
+            self.ptr = None
+
+    def __del__(self):
+        self.close()
+
+
+class PartPipeline:
+    """btr_gpu_pipeline: column parts in host memory -> decoded columns in host (or device) memory,
+    with compile / copy-in / decode / copy-out of consecutive parts overlapped."""
+
+    def __init__(self, ctx, slots=3):
+        self.ctx = ctx
+        self.lib = ctx.lib
+        h = C.c_void_p()
+        N.check(self.lib.btr_gpu_pipeline_create(ctx.handle, slots, C.byref(h)))
+        self.handle = h
+
+    def acquire(self, nbytes):
+        """uint8 view of the next slot's pinned input buffer (at least nbytes long)."""
+        p = C.c_void_p()
+        N.check(self.lib.btr_gpu_pipeline_acquire(self.handle, nbytes, C.byref(p)))
+        return np.ctypeslib.as_array((C.c_uint8 * max(nbytes, 1)).from_address(p.value))[:nbytes]
+
+    def submit(self, part, host_dst=None, dev_dst=None, dst_bytes=0, host_nullmap=None, dev_nullmap=None,
+               nullmap_bytes=0):
+        """`part`: uint8 array holding the part image; destinations are raw addresses."""
+        job = N.PartJob()
+        job.host_part = part.ctypes.data
+        job.bytes = part.size
+        job.host_dst, job.dev_dst, job.dst_bytes = host_dst, dev_dst, dst_bytes
+        job.host_nullmap_dst, job.dev_nullmap_dst, job.nullmap_bytes = host_nullmap, dev_nullmap, nullmap_bytes
+        N.check(self.lib.btr_gpu_pipeline_submit(self.handle, C.byref(job)))
+
+    def drain(self):
+        st, first = C.c_uint32(), C.c_uint64()
+        N.check(self.lib.btr_gpu_pipeline_drain(self.handle, C.byref(st), C.byref(first)))
+        return st.value
+
+    @property
+    def stats(self):
+        s = N.PipelineStats()
+        N.check(self.lib.btr_gpu_pipeline_stats(self.handle, C.byref(s)))
+        return s
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.btr_gpu_pipeline_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        self.close()
+
+
 def current_stream_ptr():
     """The raw hipStream_t of torch's current stream (0 = default stream)."""
     import torch

@@ -1235,3 +1235,5 @@ btr_status btr_gpu_synchronize(btr_gpu_ctx* ctx, void* hip_stream) {
 }
 
 }  // extern "C"
+
+#include "pipeline.hip"

@@ -8,7 +8,9 @@ decompression-speed.cpp:113-170):
   column<c>_part<p>        a column part: {u32 num_chunks; u32 offsets[]} then 16-byte aligned
                            ColumnChunkMeta chunks (storage/Chunk.cpp:250-295); a part takes chunks
                            while it stays within 16 MiB (storage/Chunk.cpp:12, 228-243)
-A part file is exactly the "part image" BtrReader takes, so reading is np.fromfile + BtrReader.
+A part file is exactly the "part image" BtrReader takes. BtrDirectory streams the part files through
+the library's part pipeline: file p + 1 is read into a pinned buffer while part p is copied to the
+GPU, decoded and copied back.
 """
 import os
 import struct
@@ -82,25 +84,86 @@ def read_metadata(path):
 
 
 class BtrDirectory:
-    """A relation directory opened for GPU decoding: one BtrReader per column part."""
+    """A relation directory opened for GPU decoding (the file loop of
+    tools/conversion/decompression-speed.cpp:113-170)."""
 
-    def __init__(self, path, ctx=None, device=0):
-        from .reader import BtrReader
+    def __init__(self, path, ctx=None, device=0, slots=3):
         self.path = path
         self.ctx = ctx or api.GpuContext(device)
         self.num_chunks, self.columns = read_metadata(path)
-        self.readers = []
-        for c, (_, parts) in enumerate(self.columns):
-            self.readers.append([
-                BtrReader(np.fromfile(os.path.join(path, f"column{c}_part{p}"), dtype=np.uint8), ctx=self.ctx)
-                for p in range(parts)])
+        self.pipeline = api.PartPipeline(self.ctx, slots)
+        self._readers = {}
 
-    def decode_column(self, column):
-        """Decodes every part of a column on the GPU; returns the host array."""
-        parts = []
-        for r in self.readers[column]:
-            r.decodeAll()
-            parts.append(r.column_host())
-        if not parts:
-            return np.empty(0, dtype=np.int32)
-        return np.concatenate(parts)
+    def part_path(self, column, part):
+        return os.path.join(self.path, f"column{column}_part{part}")
+
+    def _part_sizes(self, column):
+        """(file bytes, decoded bytes with 16-byte aligned chunk starts, rows) per part, from the
+        chunk envelopes alone: 12 bytes per chunk are read, not the payloads."""
+        sizes = []
+        for p in range(self.columns[column][1]):
+            with open(self.part_path(column, p), "rb") as f:
+                total = os.fstat(f.fileno()).st_size
+                (n,) = struct.unpack("<I", f.read(4))
+                if 4 + 4 * n > total:
+                    raise ValueError("part file shorter than its chunk table")
+                offsets = struct.unpack(f"<{n}I", f.read(4 * n))
+                decoded = rows = 0
+                pieces = []  # (offset inside the part's output, bytes) per chunk
+                for off in offsets:
+                    if off + 12 > total:
+                        raise ValueError("chunk offset past the end of the part file")
+                    f.seek(off)
+                    env = f.read(12)
+                    tuples = struct.unpack_from("<I", env, 8)[0]
+                    decoded = (decoded + 15) // 16 * 16
+                    pieces.append((decoded, tuples * (8 if env[2] == 1 else 4)))
+                    decoded += pieces[-1][1]
+                    rows += tuples
+            sizes.append((total, decoded, rows, pieces))
+        return sizes
+
+    def decode_column(self, column, with_nullmap=False, out=None):
+        """Streams every part of a column through the GPU. Returns the column as a host array (a
+        view of pinned memory unless `out`, an api.PinnedBuffer, is given); with_nullmap adds the
+        byte-per-row validity array."""
+        ctype = self.columns[column][0]
+        dtype = np.float64 if ctype == 1 else np.int32
+        sizes = self._part_sizes(column)
+        starts, at = [], 0
+        for _, decoded, _, _ in sizes:
+            at = (at + 15) // 16 * 16
+            starts.append(at)
+            at += decoded
+        total_rows = sum(r for _, _, r, _ in sizes)
+        out = out or api.PinnedBuffer(at + 16)
+        if out.nbytes < at:
+            raise ValueError("output buffer too small for the column")
+        nm = api.PinnedBuffer(total_rows + 16) if with_nullmap else None
+        row_at = 0
+        for p, (nbytes, decoded, rows, _) in enumerate(sizes):
+            buf = self.pipeline.acquire(nbytes)
+            with open(self.part_path(column, p), "rb") as f:
+                if f.readinto(memoryview(buf)) != nbytes:
+                    raise IOError("short read of a column part file")
+            self.pipeline.submit(buf, host_dst=out.ptr + starts[p], dst_bytes=decoded,
+                                 host_nullmap=(nm.ptr + row_at) if nm else None, nullmap_bytes=rows if nm else 0)
+            row_at += rows
+        self.pipeline.drain()
+        self._keep = (out, nm)
+        # Chunk starts are 16-byte aligned; full 64k-row blocks leave no gaps, so the usual column is
+        # one contiguous view. Only a ragged block in the middle of a column needs the pieces joined.
+        pieces = [(s + o, n) for s, (_, _, _, ps) in zip(starts, sizes) for o, n in ps]
+        if all(a + n == b for (a, n), (b, _) in zip(pieces, pieces[1:])):
+            values = out.array[:at].view(dtype)
+        else:
+            values = np.concatenate([out.array[a:a + n].view(dtype) for a, n in pieces])
+        return (values, nm.array[:total_rows]) if with_nullmap else values
+
+    def reader(self, column, part):
+        """A device-resident BtrReader over one part (getters, readColumn of single chunks)."""
+        from .reader import BtrReader
+        key = (column, part)
+        if key not in self._readers:
+            self._readers[key] = BtrReader(np.fromfile(self.part_path(column, part), dtype=np.uint8), ctx=self.ctx)
+        return self._readers[key]

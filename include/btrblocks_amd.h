@@ -263,6 +263,52 @@ btr_status btr_gpu_plan_check(btr_gpu_ctx* ctx, btr_gpu_plan* plan, void* hip_st
 btr_status btr_gpu_decode_chunk_host(btr_gpu_ctx* ctx, const void* chunk, size_t bytes, void* dst,
                                      size_t dst_bytes, uint8_t* nullmap_dst);
 
+/* ------------------------------------------------------------------------------------------
+ * Streaming decode of column parts that start in host memory.
+ * Stands in for the loop of tools/conversion/decompression-speed.cpp:160-170 + 205-238 (read every
+ * column<c>_part<p> file, construct a BtrReader over it, readColumn every chunk) when the parts do
+ * not fit on the device at once or arrive one by one. Per part: header walk and program
+ * compilation on the host, part image host -> device, decode, decoded column device -> host; the
+ * four stages of consecutive parts overlap on three HIP streams. A pipeline owns `slots` (0 = 3)
+ * sets of device buffers, grown on demand and reused.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct btr_gpu_pipeline btr_gpu_pipeline;
+typedef struct btr_part_job {
+  const void* host_part;     /* column part image (storage/Chunk.hpp:95-98); pinned memory copies fastest */
+  size_t bytes;
+  void* host_dst;            /* decoded chunks back to back, every chunk start 16-byte aligned; or NULL */
+  void* dev_dst;             /* non-NULL: decode straight to this device buffer (host_dst is then optional) */
+  size_t dst_bytes;
+  uint8_t* host_nullmap_dst; /* byte per row, chunks back to back; or NULL */
+  uint8_t* dev_nullmap_dst;  /* or NULL */
+  size_t nullmap_bytes;
+} btr_part_job;
+typedef struct btr_pipeline_stats {
+  uint64_t parts, chunks, tuples;
+  uint64_t stored_bytes;     /* part bytes copied in      */
+  uint64_t decoded_bytes;    /* column bytes decoded      */
+  double compile_seconds;    /* host time in the header walk + program compilation           */
+  double wait_seconds;       /* host time blocked on a slot whose previous part was in flight */
+} btr_pipeline_stats;
+btr_status btr_gpu_pipeline_create(btr_gpu_ctx* ctx, uint32_t slots, btr_gpu_pipeline** out);
+void btr_gpu_pipeline_destroy(btr_gpu_pipeline* pipeline);
+/* Pinned host buffer of the slot the next submit will use, at least `bytes` long: read the part
+ * file straight into it, then pass it as btr_part_job::host_part. Blocks while that slot's
+ * previous part is still in flight. Optional - any host pointer may be submitted, but it must stay
+ * untouched until the part has been copied (btr_gpu_pipeline_drain, or `slots` later submits). */
+btr_status btr_gpu_pipeline_acquire(btr_gpu_pipeline* pipeline, size_t bytes, void** host_buffer);
+/* Enqueues one part; returns once its copies and launches are queued. Destinations must stay
+ * valid until btr_gpu_pipeline_drain. */
+btr_status btr_gpu_pipeline_submit(btr_gpu_pipeline* pipeline, const btr_part_job* job);
+/* Waits for every submitted part. *status_or is the OR of the kernels' status words since the last
+ * drain, *first_bad_part the submit index of the first part with a non-zero word;
+ * BTR_ERR_CORRUPT when any is set (as btr_gpu_plan_check). */
+btr_status btr_gpu_pipeline_drain(btr_gpu_pipeline* pipeline, uint32_t* status_or, uint64_t* first_bad_part);
+btr_status btr_gpu_pipeline_stats(const btr_gpu_pipeline* pipeline, btr_pipeline_stats* out);
+/* Pinned host memory (hipHostMalloc / hipHostFree) for part images and decoded columns. */
+btr_status btr_host_alloc(size_t bytes, void** out);
+btr_status btr_host_free(void* ptr);
+
 /* Thin wrappers over hipMalloc / hipFree / hipMemcpy for callers without a HIP toolchain. */
 btr_status btr_gpu_malloc(btr_gpu_ctx* ctx, size_t bytes, void** out);
 btr_status btr_gpu_free(btr_gpu_ctx* ctx, void* ptr);
