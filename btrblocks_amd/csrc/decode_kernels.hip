@@ -2383,8 +2383,9 @@ __device__ __forceinline__ void pfor_decode(const Ctx& c, const Step& s) {
   const u8* base = c.src + uniform(s.a[0]);
   const u32 W = uniform(s.a[1]);
   const u32 desc0 = c.consts_off + 4 * uniform(s.a[2]);
-  const u32 pages = uniform(s.a[3]) & 0x7FFFFFFFu;
-  const bool delta = (uniform(s.a[3]) >> 31) != 0;
+  const u32 pages = uniform(s.a[3]) & PFOR_PAGES_MASK;
+  const bool delta = (uniform(s.a[3]) & PFOR_DELTA_BIT) != 0;
+  const bool may_merge = (uniform(s.a[3]) & PFOR_NO_MERGE) == 0;  // the work area holds the merge tables
   const Tab out = resolve_tab(c, uniform(s.a[4]));
   const u32 work = seq_lds(c, uniform(s.a[5]));
   const u32 table_off = work, bytes_lds = work + 4096, tail_off = work + 8192, packed_lds = work + 9472,
@@ -2599,7 +2600,7 @@ __device__ __forceinline__ void pfor_decode(const Ctx& c, const Step& s) {
     for (u32 sb = 0; sb < blocks; sb += kSubBlocks) {
     const u32 se = sb + kSubBlocks < blocks ? sb + kSubBlocks : blocks;
     const u32 e_first = uniform(lds32(ebase_off + 4 * sb)), e_last = se < blocks ? uniform(lds32(ebase_off + 4 * se)) : total_exc;
-    const bool merge = patch_global && e_last - e_first <= kPforExcCap;
+    const bool merge = patch_global && may_merge && e_last - e_first <= kPforExcCap;
     if (merge) {
       for (u32 w = tid; w < 8 * kSubBlocks; w += kBlockThreads) lds_st32(mask_off + 4 * w, 0);
       __syncthreads();

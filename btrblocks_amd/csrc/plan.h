@@ -197,7 +197,10 @@ constexpr uint32_t kWalkScratchBytes = (1024 + 256) * 2;
 constexpr uint32_t kPforPageWords = 5 + 31 + 31;
 constexpr uint32_t kPforSubBlocks = 64;   // blocks unpacked between two exception preparations
 constexpr uint32_t kPforExcCap = 512;
-constexpr uint32_t kPforWorkBytes = 25856 + kPforExcCap * 4 + kPforSubBlocks * 32 + kPforSubBlocks * 8;
+constexpr uint32_t kPforWorkBaseBytes = 25856;  // without the three exception-merge tables (step flag PFOR_NO_MERGE)
+constexpr uint32_t kPforWorkBytes = kPforWorkBaseBytes + kPforExcCap * 4 + kPforSubBlocks * 32 + kPforSubBlocks * 8;
+// Bits of S_PFOR_DECODE's a3 above the page count.
+enum : uint32_t { PFOR_DELTA_BIT = 1u << 31, PFOR_NO_MERGE = 1u << 30, PFOR_PAGES_MASK = (1u << 30) - 1 };
 // Streams with more groups than this get jump tables; shorter ones are walked without.
 constexpr uint32_t kWalkScratchMinGroups = 64;
 constexpr uint32_t kLdsCapBytes = 160 * 1024;  // all of a gfx950 CU's LDS; typical chunks need 5-40 KiB

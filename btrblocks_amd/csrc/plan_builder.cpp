@@ -336,7 +336,7 @@ struct Builder {
     consts.push_back((uint32_t)in);  // first word of the VariableByte tail
     const uint32_t out = add_seq(LOC_LDS, 0, n, 4);
     const uint32_t work = add_seq(LOC_LDS, 0, kPforWorkBytes / 16, 16, true);
-    add_step(S_PFOR_DECODE, (uint32_t)payload, words, consts_at, pages | (delta ? 1u << 31 : 0u), out, work);
+    add_step(S_PFOR_DECODE, (uint32_t)payload, words, consts_at, pages | (delta ? PFOR_DELTA_BIT : 0u), out, work);
     pfor_outputs.push_back(out);
     needed += BP_DATA + (uint64_t)words * 4;
     desc = delta ? "PFOR_DELTA" : "PFOR";
@@ -741,12 +741,24 @@ void build_program(const ColumnSource& src, BuiltProgram& out) {
           bld.seqs[walk_scratch[k]].count = 0;
         }
       for (Step& st : bld.bp_steps) st.a[1] = NONE;
-      lds = 0;
-      for (auto& s : bld.seqs)
-        if (s.loc == LOC_LDS && s.must_lds && s.must_lds != 3) {
-          s.off = (uint32_t)lds;
-          lds += seq_bytes(s);
-        }
+      auto place_mandatory = [&]() {
+        lds = 0;
+        for (auto& s : bld.seqs)
+          if (s.loc == LOC_LDS && s.must_lds && s.must_lds != 3) {
+            s.off = (uint32_t)lds;
+            lds += seq_bytes(s);
+          }
+      };
+      place_mandatory();
+      if (table_base + lds > kLdsCapBytes) {
+        // still too large: PFOR steps patch in place and do without their exception-merge tables
+        for (Step& st : bld.steps)
+          if (st.kind == S_PFOR_DECODE) {
+            st.a[3] |= PFOR_NO_MERGE;
+            bld.seqs[st.a[5]].count = kPforWorkBaseBytes / 16;
+          }
+        place_mandatory();
+      }
     }
     {
       // one shared region for the transient tables, sized for the largest

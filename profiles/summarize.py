@@ -29,7 +29,13 @@ fetch, frows = per_kernel(os.path.join(out, f"{tag}_pmc_fetch", f"{tag}_counter_
 write, wrows = per_kernel(os.path.join(out, f"{tag}_pmc_write", f"{tag}_counter_collection.csv"), "WRITE_SIZE")
 
 bench = json.loads(open(os.path.join(out, f"{tag}_bench.json")).read().strip().splitlines()[-1])
-cols = bench["roofline"]["per_column"]
+cols = dict(bench["roofline"]["per_column"])
+try:  # the counter runs decode more columns than the default line (PFOR, fill, copy): take their byte counts too
+    pmc_line = [l for l in open(os.path.join(out, f"{tag}_pmc_fetch.log")) if l.startswith("{")][-1]
+    for name, c in json.loads(pmc_line)["roofline"]["per_column"].items():
+        cols.setdefault(name, c)
+except (OSError, IndexError, KeyError, ValueError):
+    pass
 summary = {"unit": "bytes", "convention": "2 * FETCH_SIZE * 1024 + WRITE_SIZE * 1024 per launch", "bytes_per_launch": {},
            "detail": {}}
 # The generic integer kernel decodes three columns in the counter runs (rle, onevalue, uncompressed), launched
@@ -50,9 +56,13 @@ for k in sorted(set(fetch) | set(write)):
             summary["bytes_per_launch"][k] = round(rd + wr)
 for name, c in cols.items():
     for k in c["kernels"]:
-        if k in summary["detail"]:
-            summary["detail"][k]["algorithmic_bytes"] = c["needed_bytes"] + c["decoded_bytes"]
-            summary["detail"][k]["column"] = name
+        key = k if f"{k}[{name}]" not in summary["detail"] else f"{k}[{name}]"
+        if key in summary["detail"] and "column" not in summary["detail"][key]:
+            det = summary["detail"][key]
+            det["algorithmic_bytes"] = c["needed_bytes"] + c["decoded_bytes"]
+            det["column"] = name
+            det["traffic_over_algorithmic"] = round((det["read_bytes"] + det["write_bytes"]) / det["algorithmic_bytes"], 4)
+            det["write_over_decoded"] = round(det["write_bytes"] / c["decoded_bytes"], 4)
 json.dump(summary, open(os.path.join(prof, "pmc_traffic.json"), "w"), indent=1)
 shutil.copy(os.path.join(out, f"{tag}_prof", f"{tag}_kernel_stats.csv"), os.path.join(prof, f"{tag}_kernel_stats_rocprofv3.csv"))
 json.dump(bench, open(os.path.join(prof, f"{tag}_bench_line.json"), "w"), indent=1)
