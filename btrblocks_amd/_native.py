@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libbtrblocks_amd.so")
+# BTR_LIB_PATH: load another build of the same library (the diagnostic build of tools/gpu_dbg.sh)
+LIB_PATH = os.environ.get("BTR_LIB_PATH") or os.path.join(_HERE, "libbtrblocks_amd.so")
 
 BTR_OK = 0
 STATUS_NAMES = {

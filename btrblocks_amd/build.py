@@ -36,12 +36,35 @@ def _sources():
     return out
 
 
+DEBUG_LIB = os.path.join(ROOT, "btrblocks_amd", "libbtrblocks_amd_dbg.so")
+
+
+def build_variant(name, defines):
+    """Experiment build: the library compiled with extra -D macros into libbtrblocks_amd_<name>.so
+    (load it with BTR_LIB_PATH). `python -m btrblocks_amd.build --variant NAME -DX -DY=1`."""
+    target = os.path.join(ROOT, "btrblocks_amd", f"libbtrblocks_amd_{name}.so")
+    cmd = [
+        HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+        "-ffp-contract=off", "-Wall", "-Wno-unused-function", *defines,
+        "-I", os.path.join(ROOT, "include"), "-I", CSRC,
+        os.path.join(CSRC, "c_api.hip"),
+        os.path.join(CSRC, "plan_builder.cpp"),
+        os.path.join(CSRC, "host", "compress.cpp"),
+        os.path.join(CSRC, "host", "codecs.cpp"),
+        "-o", target, "-lpthread",
+    ]
+    subprocess.check_call(cmd)
+    return target
+
+
 def build_library(force=False, verbose=False, debug_steps=False):
     """debug_steps: diagnostic build (-DBTR_DEBUG_STEPS) whose kernels honour the step-skipping
-    bits of BTR_DEBUG_FLAGS and record per-role wait times; never ship it."""
+    bits of BTR_DEBUG_FLAGS and record per-role wait times. It goes to a file of its own
+    (libbtrblocks_amd_dbg.so, loaded with BTR_LIB_PATH) and is never shipped."""
     srcs = _sources()
-    if not force and _newer(LIB, srcs):
-        return LIB
+    target = DEBUG_LIB if debug_steps else LIB
+    if not force and _newer(target, srcs):
+        return target
     cmd = [
         HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
         "-ffp-contract=off", "-Wall", "-Wno-unused-function",
@@ -50,14 +73,14 @@ def build_library(force=False, verbose=False, debug_steps=False):
         os.path.join(CSRC, "plan_builder.cpp"),
         os.path.join(CSRC, "host", "compress.cpp"),
         os.path.join(CSRC, "host", "codecs.cpp"),
-        "-o", LIB, "-lpthread",
+        "-o", target, "-lpthread",
     ]
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
     if debug_steps:
         cmd.insert(1, "-DBTR_DEBUG_STEPS")
     subprocess.check_call(cmd)
-    return LIB
+    return target
 
 
 def build_oracle(force=False):
@@ -89,9 +112,15 @@ def build_example(force=False):
 
 
 def main():
+    if "--variant" in sys.argv:
+        name = sys.argv[sys.argv.index("--variant") + 1]
+        print(build_variant(name, [a for a in sys.argv if a.startswith("-D")]))
+        return
     force = "--force" in sys.argv
     verbose = "--verbose" in sys.argv
-    print(build_library(force or "--debug-steps" in sys.argv, verbose, "--debug-steps" in sys.argv))
+    print(build_library(force, verbose))
+    if "--debug-steps" in sys.argv:
+        print(build_library(force, verbose, True))
     print(build_oracle(force))
     print(build_example(force))
 

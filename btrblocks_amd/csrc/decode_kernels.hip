@@ -1687,7 +1687,6 @@ __device__ __forceinline__ void stream_pseudo(const Ctx& c, const Pipe& root, co
   const u32 words = n / 64 + 1;
   const __amdgpu_buffer_rsrc_t rsrc_d = make_rsrc(bd.base, bd.bytes), rsrc_e = make_rsrc(be.base, be.bytes);
   const __amdgpu_buffer_rsrc_t dst_rsrc = make_rsrc(dst, n * 8);
-  const QuadLane q = quad_lane();
   u32 exbad = 0;
   u32 row_end = 0;  // rows the pass could produce (walker wave only; shared through LDS below)
 
@@ -1706,38 +1705,53 @@ __device__ __forceinline__ void stream_pseudo(const Ctx& c, const Pipe& root, co
     const u32x2 pair = ring_pair(((w + (bit >> 5)) << 2) & (kStreamRingBytes - 1));
     return take_bits(pair.x, pair.y, bit, b);
   };
-  // Exponent words and patch candidates of a wave's next span, in flight while the current span is
-  // produced: both come from global memory, and their latency would otherwise be paid once per span.
-  u32 pf_span = NONE, pf_eb = 0, pf_bit = 0, pf_word = 0, pf_xb = 0, pf_f = 0;
+  // Lane l produces two pairs of consecutive rows of a 256-row span P: rows 256P + 2l, + 1 (pair A,
+  // in group 2P of the exponent stream) and rows 256P + 128 + 2l, + 1 (pair B, in group 2P + 1). A
+  // pair is 16 bytes of output, so each of the span's two store instructions writes 1 KiB of
+  // consecutive bytes (whole cache lines). Both pairs sit in miniblock l / 16 of their groups, at
+  // positions 2 * (l % 16).
+  const u32 pm_sh = 24 - 8 * (lane >> 4);
+  const u32 pm_mask = (lane >> 4) ? ~(0xFFFFFFFFu >> (8 * (lane >> 4))) : 0u;
+  const u32 k2 = 2 * (lane & 15);
+  // bits of a 64-bit bitmap word below the pair's first row; the pair's two flags sit at bit 2l % 64
+  const u32 below_lo = (2 * lane & 63) < 32 ? (1u << (2 * lane & 31)) - 1 : ~0u;
+  const u32 below_hi = (2 * lane & 63) < 32 ? 0u : (1u << (2 * lane & 31)) - 1;
+  // Exponent words of a wave's next span, in flight while the current span is produced: they come
+  // from global memory, and their latency would otherwise be paid once per span. With them: the
+  // exceptions in front of each pair and the pairs' exception flags.
+  struct PairFetch {
+    u32 eb, bit, word, xb;
+    u32x2 data;
+  };
+  PairFetch pf[2];
+  u32 pf_span = NONE, pf_f = 0;
   bool pf_narrow = false;
-  u32x2 pf_data;
-  u32x4 pf_patch;
-  pf_data.x = pf_data.y = 0;
-  pf_patch.x = pf_patch.y = pf_patch.z = pf_patch.w = 0;
+#pragma unroll
+  for (u32 h = 0; h < 2; h++) pf[h].eb = pf[h].bit = pf[h].word = pf[h].xb = pf[h].data.x = pf[h].data.y = 0;
   const u32 spans_e = be.rounded >> 8;
-  // lane-constant masks: bits of a 64-bit bitmap word below the lane's first row, and where its four flags sit
-  const u32 below_lo = (4 * lane & 63) < 32 ? (1u << (4 * lane & 31)) - 1 : ~0u;
-  const u32 below_hi = (4 * lane & 63) < 32 ? 0u : (1u << (4 * lane & 31)) - 1;
   auto exp_fetch = [&](u32 P) {
     pf_span = P;
-    {
-      // exceptions in front of the lane's rows and among them; two patch candidates (one 16-byte
-      // load) cover a lane unless three of its four rows are patches
-      const u32 row = P < spans_e ? 256 * P + 4 * lane : 0;
-      const u32 w64 = row >> 6;
-      const u64 word = lds64(rk.bits_off + 8 * w64);
+    const u32 Ps = P < spans_e ? P : 0;
+    const u32 w64 = 4 * Ps + (lane >> 5);
+    u32 f = 0;
+    bool narrow = true;
+#pragma unroll
+    for (u32 h = 0; h < 2; h++) {
+      const u64 word = lds64(rk.bits_off + 8 * (w64 + 2 * h));
       const u32 wl = (u32)word, wh = (u32)(word >> 32);
-      pf_xb = lds32(rk.rank_off + 4 * w64) + (u32)__builtin_popcount(wl & below_lo) + (u32)__builtin_popcount(wh & below_hi);
-      pf_f = __builtin_amdgcn_ubfe((lane & 8) ? wh : wl, 4 * lane & 31, 4);
-      pf_patch = __builtin_amdgcn_raw_buffer_load_b128(rsrc_p, pf_xb * 8, 0, 0);
+      pf[h].xb = lds32(rk.rank_off + 4 * (w64 + 2 * h)) + (u32)__builtin_popcount(wl & below_lo) +
+                 (u32)__builtin_popcount(wh & below_hi);
+      f |= __builtin_amdgcn_ubfe((lane & 16) ? wh : wl, 2 * lane & 31, 2) << (2 * h);
+      const u64 ee = lds64(be.index_off + 8 * (2 * Ps + h));  // the same entry for every lane
+      const u32 ef = uniform((u32)ee), eh = uniform((u32)(ee >> 32));
+      narrow = narrow && widths_le5(eh);
+      pf[h].eb = __builtin_amdgcn_ubfe(eh, pm_sh, 8);
+      pf[h].word = __builtin_amdgcn_sad_u8(eh & pm_mask, 0u, ef);
+      pf[h].bit = __umul24(k2, pf[h].eb);
+      pf[h].data = __builtin_amdgcn_raw_buffer_load_b64(rsrc_e, (pf[h].word + (pf[h].bit >> 5)) * 4, 0, 0);
     }
-    const u64 ee = lds64(be.index_off + 8 * (P < spans_e ? 2 * P + q.grp : 0));
-    const u32 ef = (u32)ee, eh = (u32)(ee >> 32);
-    pf_eb = __builtin_amdgcn_ubfe(eh, q.sh, 8);
-    pf_word = __builtin_amdgcn_sad_u8(eh & q.pm, 0u, ef);
-    pf_narrow = __builtin_amdgcn_ballot_w64(!widths_le5(eh)) == 0;
-    pf_bit = __umul24(q.k4, pf_eb);
-    pf_data = __builtin_amdgcn_raw_buffer_load_b64(rsrc_e, (pf_word + (pf_bit >> 5)) * 4, 0, 0);
+    pf_f = f;
+    pf_narrow = narrow;
   };
   // rows lag up to one 256-row span behind the digits: their words may sit in the previous batch
   u32 iteration = 0;  // batches this unpack wave has seen
@@ -1753,11 +1767,10 @@ __device__ __forceinline__ void stream_pseudo(const Ctx& c, const Pipe& root, co
         return r;
       },
       [&](u32 r_lo, u32 r_hi, u32 uw) {
-        // A wave takes a 256-row span (two groups of the exponent stream) per iteration, lane l rows
-        // 4l..4l+3: the four exponents come out of one 8-byte load and one funnel shift (they are at
-        // most 5 bits wide), one bitmap word and one rank entry give the exceptions in front of all
-        // four rows, the digit indexes of the rows follow from the first one, and the rows leave as
-        // two 16-byte stores.
+        // A wave takes a 256-row span (two groups of the exponent stream) per iteration. Per pair the
+        // two exponents come out of one 8-byte load and one funnel shift (they are at most 5 bits
+        // wide), one bitmap word and one rank entry give the exceptions in front of it, one 16-byte
+        // load its (at most two) patches, and the pair leaves as one 16-byte store.
         // Span P belongs to unpack wave P % kUnpackWaves in every batch, so a wave knows its next span
         // and loads that span's exponent words while it works on the current one: the global load
         // latency would otherwise be paid once per batch, between two barriers.
@@ -1771,73 +1784,66 @@ __device__ __forceinline__ void stream_pseudo(const Ctx& c, const Pipe& root, co
         u32 P = r_lo >> 8;
         P += (uw + kUnpackWaves - P % kUnpackWaves) % kUnpackWaves;
         for (; P < (r_hi >> 8); P += kUnpackWaves) {
-          const u32 R0 = 256 * P + 4 * lane;
           if (pf_span != P) exp_fetch(P);  // first span of this wave
-          const u32 eb = pf_eb, ebit0 = pf_bit, ew = pf_word, xb = pf_xb, f = pf_f;
+          const PairFetch cur[2] = {pf[0], pf[1]};
+          const u32 f = pf_f;
           const bool narrow = pf_narrow;
-          const u32x2 ew2 = pf_data;
-          const u32x4 pt = pf_patch;
-          exp_fetch(P + kUnpackWaves);
-          u32 ex[4];
-          if (narrow) {
-            const u32 x = __builtin_amdgcn_alignbit(ew2.y, ew2.x, ebit0);
+          // patch candidates: loaded for every pair through a descriptor that returns 0 past the last
+          // patch, consumed right before the stores
+          u32x4 pt[2];
 #pragma unroll
-            for (u32 k = 0; k < 4; k++) ex[k] = __builtin_amdgcn_ubfe(x, k * eb, eb);
+          for (u32 h = 0; h < 2; h++) pt[h] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_p, cur[h].xb * 8, 0, 0);
+          exp_fetch(P + kUnpackWaves);
+          u32 ex[4];  // rows A0, A1, B0, B1
+          if (narrow) {
+#pragma unroll
+            for (u32 h = 0; h < 2; h++) {
+              const u32 x = __builtin_amdgcn_alignbit(cur[h].data.y, cur[h].data.x, cur[h].bit);
+              ex[2 * h] = __builtin_amdgcn_ubfe(x, 0u, cur[h].eb);
+              ex[2 * h + 1] = __builtin_amdgcn_ubfe(x, cur[h].eb, cur[h].eb);
+            }
           } else {  // streams no compressor writes: one exponent at a time
 #pragma unroll
             for (u32 k = 0; k < 4; k++) {
-              const u32 ebit = __umul24(q.k4 + k, eb);
-              const u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(rsrc_e, (ew + (ebit >> 5)) * 4, 0, 0);
-              ex[k] = take_bits(t.x, t.y, ebit, eb);
+              const PairFetch& pr = cur[k >> 1];
+              const u32 ebit = __umul24(k2 + (k & 1), pr.eb);
+              const u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(rsrc_e, (pr.word + (ebit >> 5)) * 4, 0, 0);
+              ex[k] = take_bits(t.x, t.y, ebit, pr.eb);
             }
           }
-          u64 pw[4];
-          if (__builtin_amdgcn_ballot_w64(__builtin_popcount(f) > 2) == 0) {
-            const u64 p0 = ((u64)pt.y << 32) | pt.x, p1 = ((u64)pt.w << 32) | pt.z;
-            pw[0] = p0;
-            pw[1] = (f & 1) ? p1 : p0;
-            pw[2] = (f & 3) ? p1 : p0;
-            pw[3] = (f & 7) ? p1 : p0;
-          } else {  // a lane with three patches among its four rows: four single loads for the whole wave
-#pragma unroll
-            for (u32 k = 0; k < 4; k++) {
-              const u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(rsrc_p, (xb + (u32)__builtin_popcount(f & ((1u << k) - 1))) * 8, 0, 0);
-              pw[k] = ((u64)t.y << 32) | t.x;
-            }
-          }
-          // digits: row k takes digit number (row - exceptions before it). The span's digits are
-          // consecutive and lie in at most three groups of the digit stream, the first one known from
-          // the exceptions in front of the span. Straight path: those groups are packed with one
-          // width below 32, so digit d sits at bit (d - first digit of the first group) * width, plus
-          // one header word per group boundary crossed.
+          // digits: a row takes digit number (row - exceptions before it). The span's digits lie in at
+          // most three groups of the digit stream, the first one known from the exceptions in front of
+          // the span. Straight path: those groups are packed with one width below 32, so digit d sits at
+          // bit (d - first digit of the first group) * width, plus one header word per group boundary
+          // crossed.
           u32 dv[4];
           {
             const u32 xb0 = uniform(lds32(rk.rank_off + 16 * P));
             u32 g0 = (256 * P - xb0) >> 7;
             g0 = g0 < groups_d ? g0 : groups_d - 1;
             const u64 en = lds64(bd.index_off + 8 * (g0 + (lane < 3 ? lane : 0)));  // lanes 0..2: the three entries
-            const u32 h = (u32)(en >> 32);
-            const u32 h0 = __builtin_amdgcn_readlane(h, 0), h1 = __builtin_amdgcn_readlane(h, 1),
-                      h2 = __builtin_amdgcn_readlane(h, 2), first0 = __builtin_amdgcn_readlane((u32)en, 0);
+            const u32 hh = (u32)(en >> 32);
+            const u32 h0 = __builtin_amdgcn_readlane(hh, 0), h1 = __builtin_amdgcn_readlane(hh, 1),
+                      h2 = __builtin_amdgcn_readlane(hh, 2), first0 = __builtin_amdgcn_readlane((u32)en, 0);
             const u32 bw = h0 & 0xFF;
             const bool straight = h0 == bw * 0x01010101u && bw < 32 && (g0 + 1 >= groups_d || h1 == h0) &&
                                   (g0 + 2 >= groups_d || h2 == h0);
-            u32 d = R0 - xb;
-            if (straight) {
-              u32 rel = d - 128 * g0;
 #pragma unroll
-              for (u32 k = 0; k < 4; k++) {
-                u32 pos;
-                asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(pos) : "v"(rel), "s"(bw), "v"((rel >> 7) << 5));
-                const u32x2 pair = ring_pair(((first0 + (pos >> 5)) << 2) & (kStreamRingBytes - 1));
-                dv[k] = __builtin_amdgcn_ubfe(__builtin_amdgcn_alignbit(pair.y, pair.x, pos), 0u, bw);
-                rel += 1 - ((f >> k) & 1);
-              }
-            } else {
+            for (u32 h = 0; h < 2; h++) {
+              const u32 d0 = 256 * P + 128 * h + 2 * lane - cur[h].xb;  // digit of the pair's first row
+              const u32 d1 = d0 + 1 - ((f >> (2 * h)) & 1);
+              if (straight) {
 #pragma unroll
-              for (u32 k = 0; k < 4; k++) {
-                dv[k] = ring_digit(d);  // beyond the last digit (patch rows only): any LDS word will do
-                d += 1 - ((f >> k) & 1);
+                for (u32 k = 0; k < 2; k++) {
+                  const u32 rel = (k ? d1 : d0) - 128 * g0;
+                  u32 pos;
+                  asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(pos) : "v"(rel), "s"(bw), "v"((rel >> 7) << 5));
+                  const u32x2 pair = ring_pair(((first0 + (pos >> 5)) << 2) & (kStreamRingBytes - 1));
+                  dv[2 * h + k] = __builtin_amdgcn_ubfe(__builtin_amdgcn_alignbit(pair.y, pair.x, pos), 0u, bw);
+                }
+              } else {  // beyond the last digit (patch rows only): any LDS word will do
+                dv[2 * h] = ring_digit(d0);
+                dv[2 * h + 1] = ring_digit(d1);
               }
             }
           }
@@ -1854,8 +1860,15 @@ __device__ __forceinline__ void stream_pseudo(const Ctx& c, const Pipe& root, co
             const u32 idx = narrow ? ex[k] : ex[k] & btrfmt::DEC_INDEX_MASK;
             idx_max = idx_max > ex[k] ? idx_max : ex[k];
             const u64 fr = lds64(frac_off + 8 * idx);
-            const u64 r = (u64)__double_as_longlong((double)(int)dv[k] * __longlong_as_double((long long)fr));
-            out[k] = ex[k] == xc.exception ? pw[k] : r;
+            out[k] = (u64)__double_as_longlong((double)(int)dv[k] * __longlong_as_double((long long)fr));
+          }
+#pragma unroll
+          for (u32 h = 0; h < 2; h++) {
+            // the pair's first exception takes the first candidate, a second one the second
+            const u64 p0 = ((u64)pt[h].y << 32) | pt[h].x, p1 = ((u64)pt[h].w << 32) | pt[h].z;
+            const bool first_is_patch = ((f >> (2 * h)) & 1) != 0;
+            if (ex[2 * h] == xc.exception) out[2 * h] = p0;
+            if (ex[2 * h + 1] == xc.exception) out[2 * h + 1] = first_is_patch ? p1 : p0;
           }
           u32x4 s0, s1;
           s0.x = (u32)out[0], s0.y = (u32)(out[0] >> 32), s0.z = (u32)out[1], s0.w = (u32)(out[1] >> 32);
@@ -1863,8 +1876,9 @@ __device__ __forceinline__ void stream_pseudo(const Ctx& c, const Pipe& root, co
 #ifdef BTR_DEBUG_STEPS
           if ((c.debug & 32) && s0.x != 0x12345678u) continue;  // diagnostic: no stores
 #endif
-          __builtin_amdgcn_raw_buffer_store_b128(s0, dst_rsrc, R0 * 8, 0, kStoreNt);
-          __builtin_amdgcn_raw_buffer_store_b128(s1, dst_rsrc, R0 * 8 + 16, 0, kStoreNt);
+          const u32 o = 2048 * P + 16 * lane;
+          __builtin_amdgcn_raw_buffer_store_b128(s0, dst_rsrc, o, 0, kStoreNt);
+          __builtin_amdgcn_raw_buffer_store_b128(s1, dst_rsrc, o + 1024, 0, kStoreNt);
         }
       });
   // plain exponents: values above 23 are no table index; codes: values outside the dictionary
@@ -2527,6 +2541,7 @@ __device__ __forceinline__ void pfor_decode(const Ctx& c, const Step& s) {
       }
       lds_st32(table_off + 16 * r + 8, before);
     }
+    __syncthreads();  // the exception bases and class indexes are read by every thread from here on
     BTR_STAMP(c, 10);
     // 3. every wave takes a contiguous quarter of the blocks, whose packed words are contiguous
     //    too, and streams them through its own 4 KiB LDS ring in 1 KiB pieces (one direct-to-LDS

@@ -158,3 +158,22 @@ def int_frequency_pool(n, seed=9, top_fraction=0.95, distinct=500):
     pool = rng.integers(0, 2**31 - 1, size=distinct).astype(np.int32)
     out[rows] = pool[rng.integers(0, distinct, size=rows.size)]
     return out
+
+
+def double_decimal_clean(n, seed=4):
+    """double_decimal without patches: every exponent is 2, no exception rows."""
+    return double_decimal(n, seed=seed, patch_fraction=0.0)
+
+
+def double_decimal_mixed(n, seed=4):
+    """Decimals of mixed magnitude (digits of 4 to 24 bits, one to four decimals) with 1 % patches:
+    digit and exponent groups whose widths change from group to group."""
+    rng = np.random.default_rng(seed)
+    bits = rng.integers(4, 25, size=(n + 31) // 32).repeat(32)[:n]
+    k = rng.integers(0, 1 << 24, size=n) >> (24 - bits)
+    e = rng.integers(1, 5, size=(n + 127) // 128).repeat(128)[:n]
+    out = k.astype(np.float64) / np.power(10.0, e)
+    m = max(1, n // 100)
+    rows = rng.choice(n, size=m, replace=False)
+    out[rows] = (k[rows].astype(np.float64) + 1.0) / 3.0
+    return out
