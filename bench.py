@@ -51,6 +51,8 @@ COLUMNS = {
     "for_rle": ("int_rle", "for(rle(bp,bp))", 8),
     "freq_dict": ("int_frequency_pool", "frequency(dict(bp))", 9),
     "pfor": ("int_outliers", "pfor", 10),
+    "pfor_few": ("int_outliers_few", "pfor", 10),
+    "pseudo_dictexp": ("double_decimal", "pseudodecimal(bp,dict(bp),uncompressed)", 4),
     "pseudo_clean": ("double_decimal_clean", "pseudodecimal(bp,bp,uncompressed)", 4),
     "pseudo_mixed": ("double_decimal_mixed", "pseudodecimal(bp,bp,uncompressed)", 4),
     "pseudo_rle": ("double_decimal_runs", "pseudodecimal(rle(dict(bp),bp),rle(bp,bp),uncompressed)", 11),

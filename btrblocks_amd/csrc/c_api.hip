@@ -167,6 +167,7 @@ struct btr_gpu_plan {
   // decode beside the main launch instead of adding their whole latency behind it.
   hipStream_t side[KERNEL_KINDS] = {};
   hipEvent_t side_done[KERNEL_KINDS] = {};
+  hipEvent_t side_go[KERNEL_KINDS] = {};  // recorded on a side stream right before its launch: the main launch waits for it
   hipEvent_t fork = nullptr;
   uint32_t main_kind = 0;
   btr_plan_stats stats{};
@@ -402,6 +403,8 @@ btr_status finish_plan(btr_gpu_ctx* ctx, std::vector<WorkItem>& items, std::vect
         if ((e = hipStreamCreateWithPriority(&plan->side[kind], hipStreamNonBlocking, greatest)) != hipSuccess)
           return cleanup(hip_fail(e, "hipStreamCreate"));
         if ((e = hipEventCreateWithFlags(&plan->side_done[kind], hipEventDisableTiming)) != hipSuccess)
+          return cleanup(hip_fail(e, "hipEventCreate"));
+        if ((e = hipEventCreateWithFlags(&plan->side_go[kind], hipEventDisableTiming)) != hipSuccess)
           return cleanup(hip_fail(e, "hipEventCreate"));
       }
     }
@@ -984,6 +987,7 @@ void btr_gpu_plan_destroy(btr_gpu_plan* plan) {
       (void)hipStreamDestroy(plan->side[kind]);
     }
     if (plan->side_done[kind]) (void)hipEventDestroy(plan->side_done[kind]);
+    if (plan->side_go[kind]) (void)hipEventDestroy(plan->side_go[kind]);
   }
   if (plan->fork) (void)hipEventDestroy(plan->fork);
   delete plan;
@@ -1025,15 +1029,21 @@ btr_status btr_gpu_decode(btr_gpu_ctx* ctx, btr_gpu_plan* plan, void* hip_stream
                        plan->d_items, plan->d_order + plan->kind_begin[kind], plan->d_programs, plan->d_status);
     return hipGetLastError();
   };
-  // the small launches fork from the caller's stream first, the main one follows on the stream
-  // itself, then the stream waits for the side streams
+  // The small launches fork from the caller's stream first, the main one follows on the stream
+  // itself, then the stream waits for the side streams. The main launch waits for an event that each
+  // side stream records right before its own launch: the few workgroups of a side launch (which may
+  // need more LDS than the main launch leaves free on any CU) are then dispatched onto an empty GPU
+  // instead of queueing for a slot until the main grid has been handed out.
   if (plan->fork) HIP_TRY(hipEventRecord(plan->fork, stream));
   for (uint32_t kind = 0; kind < KERNEL_KINDS; kind++) {
     if (!plan->side[kind]) continue;
     HIP_TRY(hipStreamWaitEvent(plan->side[kind], plan->fork, 0));
+    HIP_TRY(hipEventRecord(plan->side_go[kind], plan->side[kind]));
     HIP_TRY(launch(kind, plan->side[kind]));
     HIP_TRY(hipEventRecord(plan->side_done[kind], plan->side[kind]));
   }
+  for (uint32_t kind = 0; kind < KERNEL_KINDS; kind++)
+    if (plan->side[kind]) HIP_TRY(hipStreamWaitEvent(stream, plan->side_go[kind], 0));
   HIP_TRY(launch(plan->main_kind, stream));
   for (uint32_t kind = 0; kind < KERNEL_KINDS; kind++)
     if (plan->side[kind]) HIP_TRY(hipStreamWaitEvent(stream, plan->side_done[kind], 0));

@@ -2392,6 +2392,11 @@ __device__ __forceinline__ void pfor_wait(u32 newer) {
 #undef BTR_PFOR_WAIT_CASE
 }
 
+#ifdef BTR_EXP_PFOR_POLICY
+constexpr int kPforStorePolicy = BTR_EXP_PFOR_POLICY;
+#else
+constexpr int kPforStorePolicy = kStoreNt;
+#endif
 __device__ __forceinline__ void pfor_decode(const Ctx& c, const Step& s) {
   const u32 tid = threadIdx.x;
   const u8* base = c.src + uniform(s.a[0]);
@@ -2722,7 +2727,7 @@ __device__ __forceinline__ void pfor_decode(const Ctx& c, const Step& s) {
             const u32 o = (first + r * btrfmt::PFOR_BLOCK + 4 * lane) * 4;
             if (to_global) {
               if (wide) {
-                __builtin_amdgcn_raw_buffer_store_b128(v, out_rsrc, o, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(v, out_rsrc, o, 0, kPforStorePolicy);
                 stored++;
               } else {
                 __builtin_amdgcn_raw_buffer_store_b32(v.x, out_rsrc, o, 0, 0);
@@ -3225,7 +3230,10 @@ btr_decode_int_kernel(const WorkItem* __restrict__ items, const u32* __restrict_
   decode_block<false, false>(items, order, programs, status);
 }
 
-extern "C" __global__ void __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(5, 8)))
+#ifndef BTR_EXP_DBL_WAVES
+#define BTR_EXP_DBL_WAVES 4
+#endif
+extern "C" __global__ void __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(BTR_EXP_DBL_WAVES, 8)))
 btr_decode_dbl_kernel(const WorkItem* __restrict__ items, const u32* __restrict__ order,
                       const u8* __restrict__ programs, u32* __restrict__ status) {
   decode_block<true, false>(items, order, programs, status);
@@ -3266,13 +3274,16 @@ btr_stream_dictd_kernel(const WorkItem* __restrict__ items, const u32* __restric
 }
 
 // The generic kernels with the PFOR step (plan.h: KERNEL_PFOR_INT / KERNEL_PFOR_DBL).
-extern "C" __global__ void __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(5, 8)))
+#ifndef BTR_EXP_PFOR_WAVES
+#define BTR_EXP_PFOR_WAVES 4
+#endif
+extern "C" __global__ void __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(BTR_EXP_PFOR_WAVES, 8)))
 btr_decode_int_pfor_kernel(const WorkItem* __restrict__ items, const u32* __restrict__ order,
                            const u8* __restrict__ programs, u32* __restrict__ status) {
   decode_block<false, true>(items, order, programs, status);
 }
 
-extern "C" __global__ void __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(5, 8)))
+extern "C" __global__ void __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(BTR_EXP_PFOR_WAVES, 8)))
 btr_decode_dbl_pfor_kernel(const WorkItem* __restrict__ items, const u32* __restrict__ order,
                            const u8* __restrict__ programs, u32* __restrict__ status) {
   decode_block<true, true>(items, order, programs, status);

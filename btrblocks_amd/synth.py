@@ -177,3 +177,8 @@ def double_decimal_mixed(n, seed=4):
     rows = rng.choice(n, size=m, replace=False)
     out[rows] = (k[rows].astype(np.float64) + 1.0) / 3.0
     return out
+
+
+def int_outliers_few(n, seed=10):
+    """int_outliers with one outlier in a million values: PFOR blocks almost free of exceptions."""
+    return int_outliers(n, seed=seed, outlier_fraction=1e-6)
