@@ -255,6 +255,10 @@ def parse_args():
     ap.add_argument("--no-pipeline", action="store_true", help="skip the host-to-host leg through the part pipeline")
     ap.add_argument("--nulls", type=float, default=None, metavar="P",
                     help="give every column a random nullmap with a fraction P of valid rows and decode the byte-per-row maps too")
+    ap.add_argument("--concurrent", action="store_true",
+                    help="decode the columns of a step beside each other (btr_gpu_decode_columns); default at N > 1, "
+                         "where a rank's launches are too small to fill its GPU one at a time")
+    ap.add_argument("--serial", action="store_true", help="N > 1: one column launch after the other, as at N = 1")
     ap.add_argument("--no-verify", action="store_true", help="skip the oracle check of a sample of blocks after the timed region")
     ap.add_argument("--verify-stride", type=int, default=257, help="check every N-th chunk (and the last one)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
@@ -356,7 +360,12 @@ def run_rank(args):
             dist.barrier()
         torch.cuda.synchronize()
 
+    concurrent = (args.concurrent or world > 1) and not args.serial and len(plans) > 1
+
     def step(events=None):
+        if concurrent:  # the columns beside each other; per-launch events would time overlapped launches
+            api.decode_columns(ctx, plans, stream)
+            return
         for i, p in enumerate(plans):
             if events is not None:
                 events[i][0].record()
@@ -386,6 +395,28 @@ def run_rank(args):
         verified = sum(verify_sample(r, args.verify_stride) for r in readers)
 
     my_ms = elapsed / args.steps * 1e3
+    if concurrent:
+        # per-launch durations of the same plans, one launch after the other, outside the timed region
+        barrier()
+        for k in range(args.steps):
+            for i, p in enumerate(plans):
+                evs[k][i][0].record()
+                p.decode(stream)
+                evs[k][i][1].record()
+        barrier()
+    beside_ms = None
+    if not concurrent and world == 1 and len(plans) > 1:
+        # secondary figure: the same step with the columns beside each other
+        for _ in range(2):
+            api.decode_columns(ctx, plans, stream)
+        barrier()
+        t2 = time.perf_counter()
+        for _ in range(args.steps):
+            api.decode_columns(ctx, plans, stream)
+        barrier()
+        beside_ms = (time.perf_counter() - t2) / args.steps * 1e3
+        for p in plans:
+            p.check(stream)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -470,6 +501,8 @@ def run_rank(args):
                 "total_output_bytes": int(total_out),
                 "rank0_output_bytes": int(out_bytes),
                 "sharding": "independent block ranges per GPU, no collective",
+                "launches": ("columns beside each other (btr_gpu_decode_columns); roofline.per_column timed one launch after "
+                             "the other outside the timed region" if concurrent else "one column launch after the other"),
                 "verified_chunks": verified_all,
             },
             "roofline": {
@@ -500,6 +533,10 @@ def run_rank(args):
                 "threads": host_threads,
             },
         }
+        if beside_ms is not None:
+            line["columns_beside_each_other"] = {"ms_per_step": round(beside_ms, 4),
+                                                 "GBps": round(total_out / beside_ms / 1e6, 2),
+                                                 "what": "the same step through btr_gpu_decode_columns; not the value of this line"}
         if world == 1 and not args.no_pipeline:
             line["host"]["pipeline"] = pipeline_rate(ctx, cols)
         if world == 1 and not args.no_cpu_baseline:

@@ -189,6 +189,7 @@ SIGNATURES = {
     "btr_gpu_plan_stats": (C.c_int, [_P, C.POINTER(PlanStats)]),
     "btr_kernel_name": (C.c_char_p, [C.c_uint32]),
     "btr_gpu_decode": (C.c_int, [_P, _P, _P]),
+    "btr_gpu_decode_columns": (C.c_int, [_P, C.POINTER(C.c_void_p), C.c_size_t, _P]),
     "btr_gpu_decode_chunks_noalloc": (C.c_int, [_P, C.POINTER(ChunkDesc), C.c_size_t, _P, C.POINTER(C.c_uint32)]),
     "btr_gpu_plan_check": (C.c_int, [_P, _P, _P, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]),
     "btr_gpu_decode_chunk_host": (C.c_int, [_P, _P, C.c_size_t, _P, C.c_size_t, _P]),

@@ -231,6 +231,13 @@ class GpuContext:
         return (out, nm) if want_nullmap else out
 
 
+def decode_columns(ctx, plans, stream=None):
+    """Decodes several plans (the columns of a relation) beside each other: btr_gpu_decode_columns,
+    the counterpart of the parallel_for_each over columns in tools/conversion/decompression-speed.cpp:45-58."""
+    handles = (C.c_void_p * len(plans))(*[p.handle for p in plans])
+    N.check(ctx.lib.btr_gpu_decode_columns(ctx.handle, handles, len(plans), stream))
+
+
 class DecodePlan:
     """btr_gpu_plan over chunks whose compressed bytes are already resident on the device."""
 

@@ -146,9 +146,30 @@ StaticArea g_static_area[kMaxDevices];
 std::mutex g_static_mutex;
 }  // namespace
 
+constexpr uint32_t kColumnLanes = 8;  // streams btr_gpu_decode_columns spreads plans over
+
 struct btr_gpu_ctx {
-  int device;
-  StaticArea* area;
+  int device = 0;
+  StaticArea* area = nullptr;
+  // btr_gpu_decode_columns: a few non-blocking streams that fork from and join the caller's stream,
+  // created with the context so that the decode call itself allocates nothing. Calls on one
+  // context enqueue under the mutex (the events are reused from call to call).
+  std::mutex lanes_mutex;
+  hipStream_t lane[kColumnLanes] = {};
+  hipEvent_t lane_done[kColumnLanes] = {};
+  hipEvent_t lanes_fork = nullptr;
+  ~btr_gpu_ctx() {
+    if (!lanes_fork) return;
+    (void)hipSetDevice(device);
+    for (uint32_t k = 0; k < kColumnLanes; k++) {
+      if (lane[k]) {
+        (void)hipStreamSynchronize(lane[k]);
+        (void)hipStreamDestroy(lane[k]);
+      }
+      if (lane_done[k]) (void)hipEventDestroy(lane_done[k]);
+    }
+    (void)hipEventDestroy(lanes_fork);
+  }
 };
 
 struct btr_gpu_plan {
@@ -767,7 +788,19 @@ btr_status btr_gpu_ctx_create(int device, btr_gpu_ctx** out) {
       area->dev = ptr;
     }
   }
-  *out = new btr_gpu_ctx{device, area};
+  btr_gpu_ctx* ctx = new btr_gpu_ctx;
+  ctx->device = device;
+  ctx->area = area;
+  if ((e = hipEventCreateWithFlags(&ctx->lanes_fork, hipEventDisableTiming)) == hipSuccess)
+    for (uint32_t k = 0; k < kColumnLanes && e == hipSuccess; k++) {
+      e = hipStreamCreateWithFlags(&ctx->lane[k], hipStreamNonBlocking);
+      if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->lane_done[k], hipEventDisableTiming);
+    }
+  if (e != hipSuccess) {
+    delete ctx;
+    return hip_fail(e, "hipStreamCreate(column lanes)");
+  }
+  *out = ctx;
   return BTR_OK;
 }
 
@@ -1047,6 +1080,32 @@ btr_status btr_gpu_decode(btr_gpu_ctx* ctx, btr_gpu_plan* plan, void* hip_stream
   HIP_TRY(launch(plan->main_kind, stream));
   for (uint32_t kind = 0; kind < KERNEL_KINDS; kind++)
     if (plan->side[kind]) HIP_TRY(hipStreamWaitEvent(stream, plan->side_done[kind], 0));
+  return BTR_OK;
+}
+
+btr_status btr_gpu_decode_columns(btr_gpu_ctx* ctx, btr_gpu_plan* const* plans, size_t n, void* hip_stream) {
+  if (!ctx || (!plans && n)) return fail(BTR_ERR_INVALID_ARGUMENT, "null argument");
+  for (size_t i = 0; i < n; i++) {
+    if (!plans[i]) return fail(BTR_ERR_INVALID_ARGUMENT, "null plan");
+    if (plans[i]->device != ctx->device) return fail(BTR_ERR_INVALID_ARGUMENT, "plan " + std::to_string(i) + " belongs to another device");
+  }
+  if (n == 0) return BTR_OK;
+  if (n == 1) return btr_gpu_decode(ctx, plans[0], hip_stream);
+  DeviceGuard guard(ctx->device);
+  if (!guard.ok) return fail(BTR_ERR_DEVICE, "hipSetDevice failed");
+  hipStream_t stream = (hipStream_t)hip_stream;
+  std::lock_guard<std::mutex> lock(ctx->lanes_mutex);
+  const uint32_t used = (uint32_t)std::min<size_t>(n, kColumnLanes);
+  HIP_TRY(hipEventRecord(ctx->lanes_fork, stream));
+  for (uint32_t k = 0; k < used; k++) HIP_TRY(hipStreamWaitEvent(ctx->lane[k], ctx->lanes_fork, 0));
+  for (size_t i = 0; i < n; i++) {
+    const btr_status st = btr_gpu_decode(ctx, plans[i], ctx->lane[i % kColumnLanes]);
+    if (st != BTR_OK) return st;
+  }
+  for (uint32_t k = 0; k < used; k++) {
+    HIP_TRY(hipEventRecord(ctx->lane_done[k], ctx->lane[k]));
+    HIP_TRY(hipStreamWaitEvent(stream, ctx->lane_done[k], 0));
+  }
   return BTR_OK;
 }
 

@@ -236,6 +236,15 @@ const char* btr_kernel_name(uint32_t k);
  * BtrReader::readColumn (BtrReader.cpp:45-71) for all chunks at once. */
 btr_status btr_gpu_decode(btr_gpu_ctx* ctx, btr_gpu_plan* plan, void* hip_stream);
 
+/* Enqueues the decode of several plans (typically the columns of one relation) so that they run
+ * beside each other: the plans are spread over a few streams owned by the context, which fork from
+ * `hip_stream` and join it again by events; work queued behind the call sees every plan decoded.
+ * Asynchronous; allocates nothing. Stands in for the tbb::parallel_for_each over columns in
+ * tools/conversion/decompression-speed.cpp:45-58. Launches that are too small to fill the GPU
+ * (a rank's shard of a relation, the last round of a large launch) overlap this way; the plans'
+ * destinations must not overlap. Two launches of the same plan must not overlap either. */
+btr_status btr_gpu_decode_columns(btr_gpu_ctx* ctx, btr_gpu_plan* const* plans, size_t n, void* hip_stream);
+
 /* btr_gpu_plan_create + btr_gpu_decode (+ btr_gpu_plan_check) in one call that allocates nothing:
  * no hipMalloc / hipFree, no stream or event creation. It has no counterpart in the reference; it
  * exists for callers that cannot allocate - tight serving loops and harnesses that forbid

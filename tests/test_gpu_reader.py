@@ -240,3 +240,35 @@ def test_relation_directory_round_trip(gpu_ctx, tmp_path):
     for c, want in enumerate(cols):
         got = d.decode_column(c)
         assert np.array_equal(got.view(np.uint8), want.view(np.uint8))
+
+
+@pytest.mark.gpu
+def test_columns_decoded_beside_each_other_match_one_after_the_other(gpu_ctx):
+    """btr_gpu_decode_columns (decompression-speed.cpp:45-58 decodes columns in parallel) against
+    btr_gpu_decode per plan: same bytes, twice in a row, with more plans than lanes."""
+    import torch
+    from btrblocks_amd import api
+    specs = [("int_rle", "rle(bp,bp)"), ("int_dict", "dict(bp)"), ("int_for", "for(bp)"), ("double_decimal", "pseudodecimal"),
+             ("int_outliers", "pfor"), ("double_dict", "dict(bp)"), ("double_runs", "rle(uncompressed,bp)"),
+             ("int_frequency_pool", "frequency(dict(bp))"), ("int_constant", "onevalue"), ("int_rle_pool", "rle(dict(bp),bp)")]
+    readers = []
+    for k, (gen, spec) in enumerate(specs):
+        values = getattr(synth, gen)(3 * 65536 + 1000 * k)
+        readers.append(B.BtrReader(B.compress_column(values, None, spec), ctx=gpu_ctx))
+    plans = [r.plan(None, False) for r in readers]
+    stream = api.current_stream_ptr()
+    for r in readers:
+        r.d_out.zero_()
+    for p in plans:
+        p.decode(stream)
+    torch.cuda.synchronize()
+    want = [r.d_out.clone() for r in readers]
+    for _ in range(2):
+        for r in readers:
+            r.d_out.zero_()
+        api.decode_columns(gpu_ctx, plans, stream)
+        torch.cuda.synchronize()
+        for p in plans:
+            assert p.check(stream) == 0
+        for r, w in zip(readers, want):
+            assert torch.equal(r.d_out, w)
