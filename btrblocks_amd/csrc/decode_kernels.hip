@@ -2301,6 +2301,9 @@ __device__ __forceinline__ void bitmap_set(const Ctx& c, const Step& s) {
 // Run lengths -> run starts (exclusive scan) -> one start flag per run (templated/RLE.hpp:164-191
 // expands runs back to back; the start of run r is the sum of the lengths before it). Every
 // thread owns a contiguous slice of runs, so one block-wide scan covers any run count.
+// Set by bitmap_starts when it could not (or was not asked to) fill the rank table of its bitmap.
+__device__ __forceinline__ u32 rank_pending_word(const Ctx& c) { return c.red_off + 52; }
+constexpr u32 kRankFuseWords = 8;
 __device__ __forceinline__ void bitmap_starts(const Ctx& c, const Step& s) {
   const Tab len = resolve_tab(c, uniform(s.a[0]));
   const u32 bits_off = seq_lds(c, uniform(s.a[1]));
@@ -2314,16 +2317,38 @@ __device__ __forceinline__ void bitmap_starts(const Ctx& c, const Step& s) {
     bad |= l <= 0;
     sum += l > 0 ? (u32)l : 0u;
   }
+  // The rank table (start flags in front of every 64-row word) falls out of the same scan: runs
+  // 0..r start in front of word w exactly when start(r) < 64 w <= start(r + 1), so the thread that
+  // owns run r writes r + 1 into the words its run reaches. A run that reaches many words would
+  // serialise that: it is left to the rank step behind this one, which otherwise finds nothing to do.
+  const u32 rank_seq = uniform(s.a[2]);
+  const u32 rank_off = rank_seq == NONE ? 0u : seq_lds(c, rank_seq);
+  const u32 words = nbits / 64 + 1;
+  if (threadIdx.x == 0) {
+    lds_st32(rank_pending_word(c), rank_seq == NONE ? 1u : 0u);
+    if (rank_seq != NONE) lds_st32(rank_off, 0);
+  }
   u32 total;
   u32 start = block_exclusive_scan(c, sum, &total);
+  bool left_over = false;
   for (u32 r = r_lo; r < r_hi; r++) {
     const int l = (int)tab_ld32(len, r);
     if (start < nbits)
       bitmap_or(bits_off, start);
     else
       bad = 1;
-    start += l > 0 ? (u32)l : 0u;
+    const u32 next = start + (l > 0 ? (u32)l : 0u);
+    if (rank_seq != NONE) {
+      const u32 w_lo = (start >> 6) + 1, w_hi = (next >> 6) < words - 1 ? (next >> 6) : words - 1;
+      if (w_hi >= w_lo && w_hi - w_lo >= kRankFuseWords) {
+        left_over = true;
+      } else {
+        for (u32 w = w_lo; w <= w_hi; w++) lds_st32(rank_off + 4 * w, r + 1);
+      }
+    }
+    start = next;
   }
+  if (left_over) lds_st32(rank_pending_word(c), 1);
   if (total != nbits && threadIdx.x == 0) bad = 1;
   if (bad) raise(c, ST_RLE_COUNTS);
 }
@@ -2937,6 +2962,8 @@ __device__ __forceinline__ void bitmap_rank(const Ctx& c, const Step& s) {
   const Seq& bm = seq_at(c, uniform(s.a[1]));
   const u32 bits_off = c.table_base + uniform(bm.off), words = uniform(bm.count);
   const u32 rank_off = seq_lds(c, uniform(s.a[2]));
+  // a bitmap of run starts: the start-flag step in front of this one has usually filled the table
+  if (uniform(s.a[0]) == 1 && uniform(lds32(rank_pending_word(c))) == 0) return;
   const u32 per = (words + THREADS - 1) / THREADS;
   const u32 w_lo = threadIdx.x * per < words ? threadIdx.x * per : words;
   const u32 w_hi = w_lo + per < words ? w_lo + per : words;

@@ -78,10 +78,12 @@ enum : uint8_t {
   S_BITMAP_CLEAR = 2,   // a1 seq bitmap
   S_BITMAP_SET = 3,     // a0 src byte offset, a1 seq bitmap, a2 element count, a3 first row of the
                         // container (key << 16), a4 bit count, a5 element kind (SET_*)
-  S_BITMAP_STARTS = 4,  // a0 seq run lengths (s32), a1 seq bitmap, a3 bit count, a4 runs:
-                        // exclusive-scans the lengths and sets one bit per run start
+  S_BITMAP_STARTS = 4,  // a0 seq run lengths (s32), a1 seq bitmap, a2 seq rank (or NONE), a3 bit count, a4 runs:
+                        // exclusive-scans the lengths, sets one bit per run start and, when no run reaches
+                        // more than a few 64-row words, fills the rank table as well
   S_BITMAP_EQ = 5,      // a0 pipe id, a1 seq bitmap, a3 bit count, a4 value: bit i = (pipe[i] == value)
-  S_BITMAP_RANK = 6,    // a1 seq bitmap, a2 seq rank, a3 bit count, a4 expected popcount (or NONE),
+  S_BITMAP_RANK = 6,    // a0 1 = the bitmap holds run starts and S_BITMAP_STARTS may have filled the table already
+                        // (else NONE), a1 seq bitmap, a2 seq rank, a3 bit count, a4 expected popcount (or NONE),
                         // a5 status bit to raise on a mismatch
   S_NULLMAP = 7,        // a0 nullmap type, a1 seq bitmap (REGULAR/FLIPPED, else NONE), a3 row count
   S_PFOR_DECODE = 9,    // see below

@@ -399,8 +399,8 @@ struct Builder {
     add_step(S_BITMAP_CLEAR, NONE, bm.bits);
     steps.back().no_barrier = 1;  // the length copy touches neither the bitmap nor anything the clear reads
     add_step(S_MATERIALIZE, cp, lengths);
-    add_step(S_BITMAP_STARTS, lengths, bm.bits, NONE, n, runs);
-    add_step(S_BITMAP_RANK, NONE, bm.bits, bm.rank, n, runs, ST_RLE_COUNTS);
+    add_step(S_BITMAP_STARTS, lengths, bm.bits, bm.rank, n, runs);  // fills the rank table too unless runs are very long
+    add_step(S_BITMAP_RANK, 1, bm.bits, bm.rank, n, runs, ST_RLE_COUNTS);
     const size_t rank_step = steps.size() - 1;
     const uint32_t values = as_seq(vp, n);
     // the run values are copied while the rank table is still being built: neither reads the other's output
