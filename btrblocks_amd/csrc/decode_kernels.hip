@@ -1719,15 +1719,19 @@ __device__ __forceinline__ void stream_pseudo(const Ctx& c, const Pipe& root, co
   // Exponent words of a wave's next span, in flight while the current span is produced: they come
   // from global memory, and their latency would otherwise be paid once per span. With them: the
   // exceptions in front of each pair and the pairs' exception flags.
+  // The exponent words themselves are fetched once per wave, not once per lane: the span's two groups
+  // are at most 42 consecutive words when every width is at most 5, lane j loads word j of them (one
+  // coalesced load) and the lanes pick their two words with lane permutes. Sixty-four lanes that each
+  // load their own, mostly identical, 8 bytes cost the vector cache a pass per lane: 8 % of the
+  // launch for plain exponents and 14 % for dictionary codes, whose lanes all hit the same word.
   struct PairFetch {
     u32 eb, bit, word, xb;
-    u32x2 data;
   };
   PairFetch pf[2];
-  u32 pf_span = NONE, pf_f = 0;
+  u32 pf_span = NONE, pf_f = 0, pf_words = 0, pf_first = 0;
   bool pf_narrow = false;
 #pragma unroll
-  for (u32 h = 0; h < 2; h++) pf[h].eb = pf[h].bit = pf[h].word = pf[h].xb = pf[h].data.x = pf[h].data.y = 0;
+  for (u32 h = 0; h < 2; h++) pf[h].eb = pf[h].bit = pf[h].word = pf[h].xb = 0;
   const u32 spans_e = be.rounded >> 8;
   auto exp_fetch = [&](u32 P) {
     pf_span = P;
@@ -1748,7 +1752,10 @@ __device__ __forceinline__ void stream_pseudo(const Ctx& c, const Pipe& root, co
       pf[h].eb = __builtin_amdgcn_ubfe(eh, pm_sh, 8);
       pf[h].word = __builtin_amdgcn_sad_u8(eh & pm_mask, 0u, ef);
       pf[h].bit = __umul24(k2, pf[h].eb);
-      pf[h].data = __builtin_amdgcn_raw_buffer_load_b64(rsrc_e, (pf[h].word + (pf[h].bit >> 5)) * 4, 0, 0);
+      if (h == 0) {
+        pf_first = ef - 1;  // the header of the span's first group
+        pf_words = __builtin_amdgcn_raw_buffer_load_b32(rsrc_e, (pf_first + lane) * 4, 0, 0);  // past the stream: 0
+      }
     }
     pf_f = f;
     pf_narrow = narrow;
@@ -1786,19 +1793,26 @@ __device__ __forceinline__ void stream_pseudo(const Ctx& c, const Pipe& root, co
         for (; P < (r_hi >> 8); P += kUnpackWaves) {
           if (pf_span != P) exp_fetch(P);  // first span of this wave
           const PairFetch cur[2] = {pf[0], pf[1]};
-          const u32 f = pf_f;
+          const u32 f = pf_f, span_words = pf_words, span_first = pf_first;
           const bool narrow = pf_narrow;
-          // patch candidates: loaded for every pair through a descriptor that returns 0 past the last
-          // patch, consumed right before the stores
+          // patch candidates: loaded by the (few) lanes whose pair holds an exception row, through a
+          // descriptor that returns 0 past the last patch, and consumed right before the stores. A load
+          // by all 64 lanes of what is almost always the same 16 bytes costs the vector cache a pass per lane.
           u32x4 pt[2];
 #pragma unroll
-          for (u32 h = 0; h < 2; h++) pt[h] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_p, cur[h].xb * 8, 0, 0);
+          for (u32 h = 0; h < 2; h++) {
+            pt[h].x = pt[h].y = pt[h].z = pt[h].w = 0;
+            if ((f >> (2 * h)) & 3) pt[h] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_p, cur[h].xb * 8, 0, 0);
+          }
           exp_fetch(P + kUnpackWaves);
           u32 ex[4];  // rows A0, A1, B0, B1
           if (narrow) {
 #pragma unroll
             for (u32 h = 0; h < 2; h++) {
-              const u32 x = __builtin_amdgcn_alignbit(cur[h].data.y, cur[h].data.x, cur[h].bit);
+              const u32 rel = cur[h].word + (cur[h].bit >> 5) - span_first;  // below 43
+              const u32 lo = __builtin_amdgcn_ds_bpermute(rel << 2, span_words);
+              const u32 hi = __builtin_amdgcn_ds_bpermute((rel + 1) << 2, span_words);
+              const u32 x = __builtin_amdgcn_alignbit(hi, lo, cur[h].bit);
               ex[2 * h] = __builtin_amdgcn_ubfe(x, 0u, cur[h].eb);
               ex[2 * h + 1] = __builtin_amdgcn_ubfe(x, cur[h].eb, cur[h].eb);
             }
