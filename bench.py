@@ -258,6 +258,9 @@ def parse_args():
     ap.add_argument("--concurrent", action="store_true",
                     help="decode the columns of a step beside each other (btr_gpu_decode_columns); default at N > 1, "
                          "where a rank's launches are too small to fill its GPU one at a time")
+    ap.add_argument("--beside-leg", action="store_true",
+                    help="N = 1: after the timed region, time the same step with the columns beside each other as well "
+                         "(columns_beside_each_other; its launches overlap, so leave it out of profiled runs)")
     ap.add_argument("--serial", action="store_true", help="N > 1: one column launch after the other, as at N = 1")
     ap.add_argument("--no-verify", action="store_true", help="skip the oracle check of a sample of blocks after the timed region")
     ap.add_argument("--verify-stride", type=int, default=257, help="check every N-th chunk (and the last one)")
@@ -405,7 +408,7 @@ def run_rank(args):
                 evs[k][i][1].record()
         barrier()
     beside_ms = None
-    if not concurrent and world == 1 and len(plans) > 1:
+    if args.beside_leg and not concurrent and world == 1 and len(plans) > 1:
         # secondary figure: the same step with the columns beside each other
         for _ in range(2):
             api.decode_columns(ctx, plans, stream)
