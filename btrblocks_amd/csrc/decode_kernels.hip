@@ -728,11 +728,31 @@ __device__ __forceinline__ void walk_chain(const u32 (&d)[kWalkBatch], u32 bb, u
     u32 next;
     if (m < cnt) {
       next = __builtin_amdgcn_readlane(node, m);
-    } else {  // all 64 lanes hold groups inside the batch: go on behind the last one
-      const u32 last = __builtin_amdgcn_readlane(node, 63);
+      st.g = uniform(st.g + m);
+    } else if (cnt == 64) {
+      // All 64 lanes hold groups inside the batch (narrow groups) and the table holds J^32: the next
+      // 64 groups are J^32(J^32(node)), two gathers, instead of a new table and six more rounds.
+      // Positions behind the batch map to themselves, so a lane whose chain has left the batch keeps
+      // its exit position.
+      st.g = uniform(st.g + m);
+      for (;;) {
+        const u32 node2 = lds16(jump_off + 2 * lds16(jump_off + 2 * node));
+        u32 m2 = (u32)__popcll(__ballot(node2 < kBatchWords));
+        m2 = m2 < groups - st.g ? m2 : groups - st.g;
+        emit(st.g, m2, bb + node2);
+        st.g = uniform(st.g + m2);
+        if (m2 < 64) {
+          next = __builtin_amdgcn_readlane(node2, m2);
+          break;
+        }
+        node = node2;
+      }
+      st.spec_ok = 0;
+    } else {  // fewer than 64 lanes, all inside the batch, and the chain goes on: step behind the last one
+      const u32 last = __builtin_amdgcn_readlane(node, cnt - 1);
       next = last + length_at_uniform(d, last);
+      st.g = uniform(st.g + m);
     }
-    st.g = uniform(st.g + m);
     st.pos = uniform(bb + next);
   }
 }
