@@ -2596,14 +2596,31 @@ __device__ __forceinline__ void pfor_decode(const Ctx& c, const Step& s) {
     }
     // 2. index of a block's first exception inside its width class: exceptions of the same width
     //    in the blocks before it
-    for (u32 r = tid; r < blocks; r += kBlockThreads) {
-      const u32 k = lds32(table_off + 16 * r) >> 16;
-      u32 before = 0;
-      for (u32 q = 0; q < r; q++) {
-        const u32 e = lds32(table_off + 16 * q);
-        before += (e >> 16) == k ? (e >> 8) & 0xFF : 0u;
+    //    A page rarely uses more than a few widths: one block-wide scan per width that occurs
+    //    (a page has at most 256 blocks, one per thread); with many widths every block counts the
+    //    blocks in front of it instead.
+    u32 widths_used = 0;
+    for (u32 k = 2; k <= 32; k++) widths_used += uniform(lds32(d + 4 * (5 + 31 + k - 2))) != 0;
+    if (widths_used <= 8 && blocks <= kBlockThreads) {
+      const u32 e = tid < blocks ? lds32(table_off + 16 * tid) : 0u;
+      if (tid < blocks) lds_st32(table_off + 16 * tid + 8, 0);
+      for (u32 k = 2; k <= 32; k++) {
+        if (uniform(lds32(d + 4 * (5 + 31 + k - 2))) == 0) continue;
+        const bool mine = tid < blocks && (e >> 16) == k;
+        u32 total;
+        const u32 before = block_exclusive_scan(c, mine ? (e >> 8) & 0xFF : 0u, &total);
+        if (mine) lds_st32(table_off + 16 * tid + 8, before);
       }
-      lds_st32(table_off + 16 * r + 8, before);
+    } else {
+      for (u32 r = tid; r < blocks; r += kBlockThreads) {
+        const u32 k = lds32(table_off + 16 * r) >> 16;
+        u32 before = 0;
+        for (u32 q = 0; q < r; q++) {
+          const u32 e = lds32(table_off + 16 * q);
+          before += (e >> 16) == k ? (e >> 8) & 0xFF : 0u;
+        }
+        lds_st32(table_off + 16 * r + 8, before);
+      }
     }
     __syncthreads();  // the exception bases and class indexes are read by every thread from here on
     BTR_STAMP(c, 10);
