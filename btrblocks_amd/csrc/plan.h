@@ -192,13 +192,19 @@ constexpr uint32_t kWalkScratchBytes = (1024 + 256) * 2;
 //   [9472, 25856)      a 4 KiB ring of packed block data per wave of the generic kernels; before
 //                      the blocks are unpacked the same bytes hold the jump pointers of the
 //                      byte-container chain, u16[4096 + 512], and the record offset per block, u16[256]
-//   [25856, 27904)     high bits (value << b) of the exceptions of the current sub-range of blocks, in
+//   [25856, 29952)     high bits (value << b) of the exceptions of the current sub-range of blocks, in
 //                      exception order (kPforExcCap of them; a sub-range with more is patched in memory)
-//   [27904, 29952)     a 256-bit mask of exception positions per block of the sub-range
-//   [29952, 30464)     per block, the exceptions in front of each 32-bit word of its mask (8 bytes)
+//   [29952, 34048)     a 256-bit mask of exception positions per block of the sub-range
+//   [34048, 35072)     per block, the exceptions in front of each 32-bit word of its mask (8 bytes)
+// Sub-ranges of 128 blocks (two exception preparations per page): with 64 the preparations' barriers
+// and lookup chains cost 0.38 ms per 1 GiB column instead of 0.35, with 256 the tables leave room for
+// three workgroups per CU only (0.43 ms).
 constexpr uint32_t kPforPageWords = 5 + 31 + 31;
-constexpr uint32_t kPforSubBlocks = 64;   // blocks unpacked between two exception preparations
-constexpr uint32_t kPforExcCap = 512;
+#ifndef BTR_EXP_PFOR_SUB
+#define BTR_EXP_PFOR_SUB 128
+#endif
+constexpr uint32_t kPforSubBlocks = BTR_EXP_PFOR_SUB;   // blocks unpacked between two exception preparations
+constexpr uint32_t kPforExcCap = 8 * kPforSubBlocks;
 constexpr uint32_t kPforWorkBaseBytes = 25856;  // without the three exception-merge tables (step flag PFOR_NO_MERGE)
 constexpr uint32_t kPforWorkBytes = kPforWorkBaseBytes + kPforExcCap * 4 + kPforSubBlocks * 32 + kPforSubBlocks * 8;
 // Bits of S_PFOR_DECODE's a3 above the page count.
