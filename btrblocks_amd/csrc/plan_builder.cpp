@@ -395,16 +395,18 @@ struct Builder {
     // after that step, so the length tables of all RLE nodes of a program share one region.
     const uint32_t lengths = add_seq(LOC_LDS, 0, runs, 4);
     transient.push_back(lengths);
+    // The run values are copied first and run into the bitmap clear and the length copy without a
+    // barrier (none of the three reads what another writes): the memory latencies of the two copies
+    // overlap instead of adding up.
+    const size_t before_values = steps.size();
+    const uint32_t values = as_seq(vp, n);
+    if (steps.size() == before_values + 1 && steps.back().kind == S_MATERIALIZE) steps.back().no_barrier = 1;
     const Bitmap bm = add_bitmap(n);
     add_step(S_BITMAP_CLEAR, NONE, bm.bits);
     steps.back().no_barrier = 1;  // the length copy touches neither the bitmap nor anything the clear reads
     add_step(S_MATERIALIZE, cp, lengths);
     add_step(S_BITMAP_STARTS, lengths, bm.bits, bm.rank, n, runs);  // fills the rank table too unless runs are very long
     add_step(S_BITMAP_RANK, 1, bm.bits, bm.rank, n, runs, ST_RLE_COUNTS);
-    const size_t rank_step = steps.size() - 1;
-    const uint32_t values = as_seq(vp, n);
-    // the run values are copied while the rank table is still being built: neither reads the other's output
-    if (steps.size() == rank_step + 2) steps[rank_step].no_barrier = 1;
     const uint32_t p = add_pipe(B_RLE, IS_DOUBLE, n);
     pipes[p].a[0] = bm.bits;
     pipes[p].a[1] = bm.rank;
@@ -850,7 +852,8 @@ void build_program(const ColumnSource& src, BuiltProgram& out) {
       best_step = producer;
     }
     if (best != NONE) {
-      const Step moved = bld.steps[best_step];
+      Step moved = bld.steps[best_step];
+      moved.no_barrier = 0;  // the root step right behind it reads the table
       // a step allowed to run into the moved one without a barrier gets another successor
       if (best_step > 0 && best_step + 1 != root_idx) bld.steps[best_step - 1].no_barrier = 0;
       bld.steps.erase(bld.steps.begin() + best_step);
