@@ -1396,8 +1396,18 @@ __device__ __forceinline__ void ring_walk_batch(u32 index_off, u32 jump_off, u32
 // publish() values must then be unit counts boundaries such that "lo == hi" means "no unit".
 __device__ __forceinline__ u32 ring_release_word(const Ctx& c) { return c.red_off + 40; }
 
-template <bool KEEP_PREVIOUS = false, u32 WAVES = kStreamWaves, u32 DBG = 0, bool EARLY_RELEASE = false, typename Publish,
-          typename Unpack>
+// The batches a pass starts with (as many as it keeps in flight), issued by its loading wave. A caller
+// may do this itself ahead of the pass (PREISSUED), behind a barrier after which nothing reads the ring.
+template <bool KEEP_PREVIOUS, bool EARLY_RELEASE>
+__device__ __forceinline__ void ring_issue_first(const BpView& bp, const Pipe& p) {
+  constexpr u32 ahead = KEEP_PREVIOUS && !EARLY_RELEASE ? kRingAhead - 1 : kRingAhead;
+  const u32 batches = (uniform(p.a[1]) + kBatchWords - 1) / kBatchWords;
+  const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(bp.base, bp.bytes);
+  for (u32 t = 0; t < ahead; t++) ring_issue<0>(rsrc, t, batches);
+}
+
+template <bool KEEP_PREVIOUS = false, u32 WAVES = kStreamWaves, u32 DBG = 0, bool EARLY_RELEASE = false,
+          bool PREISSUED = false, typename Publish, typename Unpack>
 __device__ __forceinline__ void ring_pass(const Ctx& c, const Pipe& p, const BpView& bp, u32 jump_off, Publish publish,
                                           Unpack unpack) {
   static_assert(!EARLY_RELEASE || KEEP_PREVIOUS, "early release refines the keep-previous schedule");
@@ -1415,7 +1425,8 @@ __device__ __forceinline__ void ring_pass(const Ctx& c, const Pipe& p, const BpV
   if (wave == WAVES - 1) {
     // ---- loader
     const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(bp.base, bp.bytes);
-    for (u32 t = 0; t < ahead; t++) ring_issue<0>(rsrc, t, batches);
+    if (!PREISSUED)
+      for (u32 t = 0; t < ahead; t++) ring_issue<0>(rsrc, t, batches);
     if (EARLY_RELEASE && lane == 0) lds_st32(ring_release_word(c), 0);
     // batches 0 and 1 landed (only batch 2 may still be in flight), then the start barrier
     ring_wait(kTwoInFlight && batches > 2);
@@ -1782,7 +1793,7 @@ __device__ __forceinline__ void stream_pseudo(const Ctx& c, const Pipe& root, co
   };
   // rows lag up to one 256-row span behind the digits: their words may sit in the previous batch
   u32 iteration = 0;  // batches this unpack wave has seen
-  ring_pass<true, kStreamWaves, 9, true>(
+  ring_pass<true, kStreamWaves, 9, true, true>(
       c, pd, bd, jump_off,
       [&](const ChainState& st) {
         // digits indexed so far -> rows that can be produced, in whole 256-row spans
@@ -1862,23 +1873,29 @@ __device__ __forceinline__ void stream_pseudo(const Ctx& c, const Pipe& root, co
             const u32 bw = h0 & 0xFF;
             const bool straight = h0 == bw * 0x01010101u && bw < 32 && (g0 + 1 >= groups_d || h1 == h0) &&
                                   (g0 + 2 >= groups_d || h2 == h0);
+            u32 dg[4];  // digit numbers of rows A0, A1, B0, B1
 #pragma unroll
             for (u32 h = 0; h < 2; h++) {
-              const u32 d0 = 256 * P + 128 * h + 2 * lane - cur[h].xb;  // digit of the pair's first row
-              const u32 d1 = d0 + 1 - ((f >> (2 * h)) & 1);
-              if (straight) {
+              dg[2 * h] = 256 * P + 128 * h + 2 * lane - cur[h].xb;  // digit of the pair's first row
+              dg[2 * h + 1] = dg[2 * h] + 1 - ((f >> (2 * h)) & 1);
+            }
+            if (straight) {
+              // all four ring reads are issued before the first one is waited for
+              u32 pos[4];
+              u32x2 pair[4];
 #pragma unroll
-                for (u32 k = 0; k < 2; k++) {
-                  const u32 rel = (k ? d1 : d0) - 128 * g0;
-                  u32 pos;
-                  asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(pos) : "v"(rel), "s"(bw), "v"((rel >> 7) << 5));
-                  const u32x2 pair = ring_pair(((first0 + (pos >> 5)) << 2) & (kStreamRingBytes - 1));
-                  dv[2 * h + k] = __builtin_amdgcn_ubfe(__builtin_amdgcn_alignbit(pair.y, pair.x, pos), 0u, bw);
-                }
-              } else {  // beyond the last digit (patch rows only): any LDS word will do
-                dv[2 * h] = ring_digit(d0);
-                dv[2 * h + 1] = ring_digit(d1);
+              for (u32 k = 0; k < 4; k++) {
+                const u32 rel = dg[k] - 128 * g0;
+                asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(pos[k]) : "v"(rel), "s"(bw), "v"((rel >> 7) << 5));
               }
+#pragma unroll
+              for (u32 k = 0; k < 4; k++) pair[k] = ring_pair(((first0 + (pos[k] >> 5)) << 2) & (kStreamRingBytes - 1));
+#pragma unroll
+              for (u32 k = 0; k < 4; k++)
+                dv[k] = __builtin_amdgcn_ubfe(__builtin_amdgcn_alignbit(pair[k].y, pair[k].x, pos[k]), 0u, bw);
+            } else {  // beyond the last digit (patch rows only): any LDS word will do
+#pragma unroll
+              for (u32 k = 0; k < 4; k++) dv[k] = ring_digit(dg[k]);
             }
           }
           if (P == (r_lo >> 8)) {
@@ -3245,6 +3262,9 @@ __device__ __forceinline__ void stream_pseudo_block(const WorkItem* __restrict__
   stamp(it, 2);
   stream_exception_bits(c, pe, resolve_bp(c, pe), rk, n / 64 + 1, n, jump_off, xc);
   stamp(it, 3);
+  // the exponent pass ended with a barrier and nothing reads the ring until the digit pass: its
+  // loading wave starts the first digit batches now, so that they land while the ranks are built
+  if (uniform(threadIdx.x >> 6) == kStreamWaves - 1) ring_issue_first<true, true>(resolve_bp(c, pd), pd);
   bitmap_rank<kStreamThreads>(c, step_at(c, root_idx - 1));
   __syncthreads();
   stamp(it, 4);
