@@ -1822,6 +1822,12 @@ __device__ __forceinline__ void stream_pseudo(const Ctx& c, const Pipe& root, co
         u32 P = r_lo >> 8;
         P += (uw + kUnpackWaves - P % kUnpackWaves) % kUnpackWaves;
         for (; P < (r_hi >> 8); P += kUnpackWaves) {
+          // the span's first digit group (from the exceptions in front of the span) and the index entries
+          // of the three groups it can touch: two dependent LDS reads, started before anything else
+          const u32 xb0 = uniform(lds32(rk.rank_off + 16 * P));
+          u32 g0 = (256 * P - xb0) >> 7;
+          g0 = g0 < groups_d ? g0 : groups_d - 1;
+          const u64 en = lds64(bd.index_off + 8 * (g0 + (lane < 3 ? lane : 0)));  // lanes 0..2: the three entries
           if (pf_span != P) exp_fetch(P);  // first span of this wave
           const PairFetch cur[2] = {pf[0], pf[1]};
           const u32 f = pf_f, span_words = pf_words, span_first = pf_first;
@@ -1863,10 +1869,6 @@ __device__ __forceinline__ void stream_pseudo(const Ctx& c, const Pipe& root, co
           // crossed.
           u32 dv[4];
           {
-            const u32 xb0 = uniform(lds32(rk.rank_off + 16 * P));
-            u32 g0 = (256 * P - xb0) >> 7;
-            g0 = g0 < groups_d ? g0 : groups_d - 1;
-            const u64 en = lds64(bd.index_off + 8 * (g0 + (lane < 3 ? lane : 0)));  // lanes 0..2: the three entries
             const u32 hh = (u32)(en >> 32);
             const u32 h0 = __builtin_amdgcn_readlane(hh, 0), h1 = __builtin_amdgcn_readlane(hh, 1),
                       h2 = __builtin_amdgcn_readlane(hh, 2), first0 = __builtin_amdgcn_readlane((u32)en, 0);
@@ -2468,11 +2470,7 @@ __device__ __forceinline__ void pfor_wait(u32 newer) {
 #undef BTR_PFOR_WAIT_CASE
 }
 
-#ifdef BTR_EXP_PFOR_POLICY
-constexpr int kPforStorePolicy = BTR_EXP_PFOR_POLICY;
-#else
-constexpr int kPforStorePolicy = kStoreNt;
-#endif
+constexpr int kPforStorePolicy = kStoreNt;  // non-temporal, as the other roots (cached stores: 5 % slower)
 __device__ __forceinline__ void pfor_decode(const Ctx& c, const Step& s) {
   const u32 tid = threadIdx.x;
   const u8* base = c.src + uniform(s.a[0]);
@@ -3328,10 +3326,8 @@ btr_decode_int_kernel(const WorkItem* __restrict__ items, const u32* __restrict_
   decode_block<false, false>(items, order, programs, status);
 }
 
-#ifndef BTR_EXP_DBL_WAVES
-#define BTR_EXP_DBL_WAVES 4
-#endif
-extern "C" __global__ void __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(BTR_EXP_DBL_WAVES, 8)))
+// 128 VGPRs (four waves per SIMD): at 96 the kernel spilled 38 registers.
+extern "C" __global__ void __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(4, 8)))
 btr_decode_dbl_kernel(const WorkItem* __restrict__ items, const u32* __restrict__ order,
                       const u8* __restrict__ programs, u32* __restrict__ status) {
   decode_block<true, false>(items, order, programs, status);
@@ -3372,16 +3368,15 @@ btr_stream_dictd_kernel(const WorkItem* __restrict__ items, const u32* __restric
 }
 
 // The generic kernels with the PFOR step (plan.h: KERNEL_PFOR_INT / KERNEL_PFOR_DBL).
-#ifndef BTR_EXP_PFOR_WAVES
-#define BTR_EXP_PFOR_WAVES 4
-#endif
-extern "C" __global__ void __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(BTR_EXP_PFOR_WAVES, 8)))
+// 128 VGPRs (four waves per SIMD): at 96 the integer kernel spilled 35 registers, and the spill
+// stores were 14 % of the launch's write requests.
+extern "C" __global__ void __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(4, 8)))
 btr_decode_int_pfor_kernel(const WorkItem* __restrict__ items, const u32* __restrict__ order,
                            const u8* __restrict__ programs, u32* __restrict__ status) {
   decode_block<false, true>(items, order, programs, status);
 }
 
-extern "C" __global__ void __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(BTR_EXP_PFOR_WAVES, 8)))
+extern "C" __global__ void __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(4, 8)))
 btr_decode_dbl_pfor_kernel(const WorkItem* __restrict__ items, const u32* __restrict__ order,
                            const u8* __restrict__ programs, u32* __restrict__ status) {
   decode_block<true, true>(items, order, programs, status);

@@ -200,10 +200,7 @@ constexpr uint32_t kWalkScratchBytes = (1024 + 256) * 2;
 // and lookup chains cost 0.38 ms per 1 GiB column instead of 0.35, with 256 the tables leave room for
 // three workgroups per CU only (0.43 ms).
 constexpr uint32_t kPforPageWords = 5 + 31 + 31;
-#ifndef BTR_EXP_PFOR_SUB
-#define BTR_EXP_PFOR_SUB 128
-#endif
-constexpr uint32_t kPforSubBlocks = BTR_EXP_PFOR_SUB;   // blocks unpacked between two exception preparations
+constexpr uint32_t kPforSubBlocks = 128;  // blocks unpacked between two exception preparations
 constexpr uint32_t kPforExcCap = 8 * kPforSubBlocks;
 constexpr uint32_t kPforWorkBaseBytes = 25856;  // without the three exception-merge tables (step flag PFOR_NO_MERGE)
 constexpr uint32_t kPforWorkBytes = kPforWorkBaseBytes + kPforExcCap * 4 + kPforSubBlocks * 32 + kPforSubBlocks * 8;
