@@ -160,7 +160,7 @@ struct btr_gpu_ctx {
   hipEvent_t lanes_fork = nullptr;
   ~btr_gpu_ctx() {
     if (!lanes_fork) return;
-    (void)hipSetDevice(device);
+    DeviceGuard guard(device);
     for (uint32_t k = 0; k < kColumnLanes; k++) {
       if (lane[k]) {
         (void)hipStreamSynchronize(lane[k]);
