@@ -2522,16 +2522,25 @@ __device__ __forceinline__ void pfor_decode(const Ctx& c, const Step& s) {
       *reinterpret_cast<u16*>(lds_raw + jt(kDead + 256 + tid)) = (u16)(kDead + 256 + tid);
       if (tid == 0) *reinterpret_cast<u16*>(lds_raw + pos_lds) = 0;
       __syncthreads();
-      for (u32 t = 0; (1u << t) < blocks; t++) {
-        if (tid >= (1u << t) && tid < (2u << t) && tid < blocks)
-          *reinterpret_cast<u16*>(lds_raw + pos_lds + 2 * tid) = (u16)lds16(jt(lds16(pos_lds + 2 * (tid - (1u << t)))));
-        u32 nj[8];  // J_(t+1) of this thread's sixteen offsets, two per register
+      // Four records per round: with the table at J^step, records step..4*step-1 follow from the ones
+      // below step by one to three table steps, then the table goes to J^(4*step) (not after the last
+      // round). Half the barriers of a round per doubling.
+      for (u32 step = 1; step < blocks; step *= 4) {
+        if (tid >= step && tid < 4 * step && tid < blocks) {
+          const u32 q = tid / step;  // 1..3
+          u32 v = lds16(jt(lds16(pos_lds + 2 * (tid - q * step))));
+          if (q > 1) v = lds16(jt(v));
+          if (q > 2) v = lds16(jt(v));
+          *reinterpret_cast<u16*>(lds_raw + pos_lds + 2 * tid) = (u16)v;
+        }
+        if (4 * step >= blocks) break;  // every thread reads its own record offset below
+        auto j4 = [&](u32 o) { return lds16(jt(lds16(jt(lds16(jt(lds16(jt(o)))))))); };
+        u32 nj[8];  // J^(4*step) of this thread's sixteen offsets, two per register
 #pragma unroll
         for (u32 i = 0; i < 8; i++)
           if (2 * i * kBlockThreads < bytes_size)
-            nj[i] = lds16(jt(lds16(jt(2 * i * kBlockThreads + tid)))) |
-                    (lds16(jt(lds16(jt((2 * i + 1) * kBlockThreads + tid)))) << 16);
-        __syncthreads();  // every thread has read J_t
+            nj[i] = j4(2 * i * kBlockThreads + tid) | (j4((2 * i + 1) * kBlockThreads + tid) << 16);
+        __syncthreads();  // every thread has read the table (and the record offsets it needed)
 #pragma unroll
         for (u32 i = 0; i < 8; i++)
           if (2 * i * kBlockThreads < bytes_size) {
