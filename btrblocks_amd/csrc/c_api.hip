@@ -128,8 +128,8 @@ btrhost::Options to_options(const btr_compress_options* o) {
 constexpr size_t kStaticBytes = 16u << 20;
 constexpr size_t kStaticMaxChunks = 256;
 constexpr size_t kStaticItemsOff = 0;                                          // WorkItem[256]
-constexpr size_t kStaticOrderOff = kStaticMaxChunks * sizeof(WorkItem);        // u32[256]
-constexpr size_t kStaticStatusOff = kStaticOrderOff + kStaticMaxChunks * 4;    // u32[256]
+constexpr size_t kStaticOrderOff = kStaticMaxChunks * sizeof(WorkItem);        // LaunchEntry[256]
+constexpr size_t kStaticStatusOff = kStaticOrderOff + kStaticMaxChunks * sizeof(LaunchEntry);  // u32[256]
 constexpr size_t kStaticProgOff = 32u << 10;                                   // programs
 constexpr size_t kStaticTablesOff = 1u << 20;                                  // table slices
 static_assert(kStaticStatusOff + kStaticMaxChunks * 4 <= kStaticProgOff, "layout of the static area");
@@ -178,7 +178,7 @@ struct btr_gpu_plan {
   WorkItem* d_items = nullptr;
   uint8_t* d_programs = nullptr;
   uint32_t* d_status = nullptr;
-  uint32_t* d_order = nullptr;  // work item indices grouped by the kernel that decodes them
+  LaunchEntry* d_order = nullptr;  // launch entries (work item index, program place) grouped by the kernel that decodes them
   size_t kind_begin[KERNEL_KINDS + 1] = {};
   uint32_t kind_lds[KERNEL_KINDS] = {};  // dynamic LDS per launch
   uint8_t* d_scratch = nullptr;
@@ -305,7 +305,7 @@ uint32_t debug_flags_from_env() {
 // Program blob, launch order and per-kind launch geometry of a set of compiled chunks.
 struct Layout {
   std::vector<uint8_t> blob;
-  std::vector<uint32_t> order;
+  std::vector<LaunchEntry> order;
   size_t kind_begin[KERNEL_KINDS + 1] = {};
   uint32_t kind_lds[KERNEL_KINDS] = {};
   uint64_t scratch = 0;
@@ -334,7 +334,7 @@ void lay_out(std::vector<WorkItem>& items, const std::vector<BuiltProgram>& prog
     lo.kind_begin[kind] = lo.order.size();
     for (size_t i = 0; i < items.size(); i++)
       if (progs[i].kernel == kind) {
-        lo.order.push_back((uint32_t)i);
+        lo.order.push_back(LaunchEntry{(uint32_t)i, items[i].prog_off, items[i].prog_bytes, 0});
         lo.kind_lds[kind] = std::max(lo.kind_lds[kind], progs[i].lds_bytes);
       }
   }
@@ -429,9 +429,9 @@ btr_status finish_plan(btr_gpu_ctx* ctx, std::vector<WorkItem>& items, std::vect
           return cleanup(hip_fail(e, "hipEventCreate"));
       }
     }
-    if ((e = hipMalloc((void**)&plan->d_order, lo.order.size() * 4)) != hipSuccess)
+    if ((e = hipMalloc((void**)&plan->d_order, lo.order.size() * sizeof(LaunchEntry))) != hipSuccess)
       return cleanup(hip_fail(e, "hipMalloc(order)"));
-    if ((e = hipMemcpy(plan->d_order, lo.order.data(), lo.order.size() * 4, hipMemcpyHostToDevice)) != hipSuccess)
+    if ((e = hipMemcpy(plan->d_order, lo.order.data(), lo.order.size() * sizeof(LaunchEntry), hipMemcpyHostToDevice)) != hipSuccess)
       return cleanup(hip_fail(e, "hipMemcpy(order)"));
   }
   stats.upload_seconds = now_s() - t_start;
@@ -1037,7 +1037,7 @@ static unsigned threads_of(uint32_t kind) {
          : kernel_is_generic(kind)                                                         ? kBlockThreads
                                                                                            : kStreamThreads;
 }
-using DecodeKernel = void (*)(const WorkItem*, const uint32_t*, const uint8_t*, uint32_t*);
+using DecodeKernel = void (*)(const WorkItem*, const LaunchEntry*, const uint8_t*, uint32_t*);
 static DecodeKernel kernel_of(uint32_t kind) {
   static const DecodeKernel kernels[KERNEL_KINDS] = {btr_decode_int_kernel,      btr_decode_dbl_kernel,
                                                      btr_stream_none_kernel,     btr_stream_add_kernel,
@@ -1147,13 +1147,13 @@ btr_status btr_gpu_decode_chunks_noalloc(btr_gpu_ctx* ctx, const btr_chunk_desc*
   // the previous call's upload must have left the pinned mirror before it is refilled
   HIP_TRY(hipEventSynchronize(area->uploaded));
   memcpy(area->staging + kStaticItemsOff, items.data(), n * sizeof(WorkItem));
-  memcpy(area->staging + kStaticOrderOff, lo.order.data(), n * 4);
+  memcpy(area->staging + kStaticOrderOff, lo.order.data(), n * sizeof(LaunchEntry));
   memset(area->staging + kStaticStatusOff, 0, kStaticMaxChunks * 4);  // status words start at zero
   memcpy(area->staging + kStaticProgOff, lo.blob.data(), lo.blob.size());
   HIP_TRY(hipMemcpyAsync(dev, area->staging, kStaticProgOff + lo.blob.size(), hipMemcpyHostToDevice, stream));
   HIP_TRY(hipEventRecord(area->uploaded, stream));
   const WorkItem* d_items = reinterpret_cast<const WorkItem*>(dev + kStaticItemsOff);
-  const uint32_t* d_order = reinterpret_cast<const uint32_t*>(dev + kStaticOrderOff);
+  const LaunchEntry* d_order = reinterpret_cast<const LaunchEntry*>(dev + kStaticOrderOff);
   uint32_t* d_status = reinterpret_cast<uint32_t*>(dev + kStaticStatusOff);
   const uint8_t* d_programs = dev + kStaticProgOff;
   for (uint32_t kind = 0; kind < KERNEL_KINDS; kind++) {  // one launch per kernel kind, back to back on the stream

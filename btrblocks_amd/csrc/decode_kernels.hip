@@ -3123,14 +3123,16 @@ __device__ __forceinline__ void stream_trailing_nullmap(const Ctx& c, const Prog
 }
 
 template <u32 THREADS, u32 BASE>
-__device__ __forceinline__ ProgramHeader load_program(const WorkItem& it, u32 item, const u8* __restrict__ programs,
-                                                      u32* __restrict__ status, Ctx& c) {
+__device__ __forceinline__ ProgramHeader load_program(const WorkItem& it, const LaunchEntry& entry,
+                                                      const u8* __restrict__ programs, u32* __restrict__ status, Ctx& c) {
+  const u32 item = entry.item;
   const u32 tid = threadIdx.x;
   c.side = uniform(it.flags) & ITEM_SIDE_LAUNCH;
   base_priority(c);  // raised for a few chunks beside a big launch
   {
-    const u32* prog = reinterpret_cast<const u32*>(programs + it.prog_off);
-    for (u32 o = tid; o < it.prog_bytes / 4; o += THREADS) lds_st32(BASE + 4 * o, prog[o]);
+    // placed by the launch entry, not by the work item: the copy does not wait for the item's load
+    const u32* prog = reinterpret_cast<const u32*>(programs + entry.prog_off);
+    for (u32 o = tid; o < entry.prog_bytes / 4; o += THREADS) lds_st32(BASE + 4 * o, prog[o]);
     if (tid == 0) status[item] = 0;  // later raise() calls are ordered behind the barrier
   }
   __syncthreads();
@@ -3179,12 +3181,13 @@ __device__ __forceinline__ void copy_to_lds(u32 lds_off, const u8* __restrict__ 
 // Lean kernel body for chunks whose program is [optional dictionary copy into LDS] + streamed
 // bit-packed root: DICT(BP), FOR(BP) and plain BP integer columns.
 template <u32 PS, bool NM>
-__device__ __forceinline__ void stream_block(const WorkItem* __restrict__ items, const u32* __restrict__ order,
+__device__ __forceinline__ void stream_block(const WorkItem* __restrict__ items, const LaunchEntry* __restrict__ order,
                                              const u8* __restrict__ programs, u32* __restrict__ status) {
-  const u32 item = order[blockIdx.x];
+  const LaunchEntry entry = order[blockIdx.x];
+  const u32 item = entry.item;
   const WorkItem it = items[item];
   Ctx c;
-  const ProgramHeader hdr = load_program<kStreamThreads, kStreamProgBase>(it, item, programs, status, c);
+  const ProgramHeader hdr = load_program<kStreamThreads, kStreamProgBase>(it, entry, programs, status, c);
   const u32 root_idx = NM ? stream_root_index(c, hdr) : hdr.n_steps - 1;
   for (u32 s = 0; s < root_idx; s++) {  // dictionary copies: a bare source sequence -> LDS
     const Step& st = step_at(c, s);
@@ -3202,13 +3205,14 @@ __device__ __forceinline__ void stream_block(const WorkItem* __restrict__ items,
 
 // DICT(BP) double chunks: [dictionary copy into LDS] + streamed root.
 template <bool NM>
-__device__ __forceinline__ void stream_dictd_block(const WorkItem* __restrict__ items, const u32* __restrict__ order,
+__device__ __forceinline__ void stream_dictd_block(const WorkItem* __restrict__ items, const LaunchEntry* __restrict__ order,
                                                    const u8* __restrict__ programs, u32* __restrict__ status) {
-  const u32 item = order[blockIdx.x];
+  const LaunchEntry entry = order[blockIdx.x];
+  const u32 item = entry.item;
   const WorkItem it = items[item];
   Ctx c;
   stamp(it, 0);
-  const ProgramHeader hdr = load_program<kDictdThreads, kStreamProgBase>(it, item, programs, status, c);
+  const ProgramHeader hdr = load_program<kDictdThreads, kStreamProgBase>(it, entry, programs, status, c);
   const u32 root_idx = NM ? stream_root_index(c, hdr) : hdr.n_steps - 1;
   for (u32 s = 0; s < root_idx; s++) {
     const Step& st = step_at(c, s);
@@ -3227,13 +3231,14 @@ __device__ __forceinline__ void stream_dictd_block(const WorkItem* __restrict__ 
 // PSEUDODECIMAL(BP, BP, raw patches) chunks. The program is [clear bitmap, rank, streamed root]:
 // the exception bitmap is filled by a ring pass over the exponent stream between the first two.
 template <bool NM>
-__device__ __forceinline__ void stream_pseudo_block(const WorkItem* __restrict__ items, const u32* __restrict__ order,
+__device__ __forceinline__ void stream_pseudo_block(const WorkItem* __restrict__ items, const LaunchEntry* __restrict__ order,
                                                     const u8* __restrict__ programs, u32* __restrict__ status) {
-  const u32 item = order[blockIdx.x];
+  const LaunchEntry entry = order[blockIdx.x];
+  const u32 item = entry.item;
   const WorkItem it = items[item];
   Ctx c;
   stamp(it, 0);
-  const ProgramHeader hdr = load_program<kStreamThreads, kStreamProgBase>(it, item, programs, status, c);
+  const ProgramHeader hdr = load_program<kStreamThreads, kStreamProgBase>(it, entry, programs, status, c);
   stamp(it, 1);
   const u32 root_idx = NM ? stream_root_index(c, hdr) : hdr.n_steps - 1;
   const Step& root = step_at(c, root_idx);
@@ -3281,14 +3286,15 @@ __device__ __forceinline__ void stream_pseudo_block(const WorkItem* __restrict__
 }
 
 template <bool DOUBLE_KERNEL, bool WITH_PFOR>
-__device__ __forceinline__ void decode_block(const WorkItem* __restrict__ items, const u32* __restrict__ order,
+__device__ __forceinline__ void decode_block(const WorkItem* __restrict__ items, const LaunchEntry* __restrict__ order,
                                     const u8* __restrict__ programs, u32* __restrict__ status) {
-  const u32 item = order[blockIdx.x];
+  const LaunchEntry entry = order[blockIdx.x];
+  const u32 item = entry.item;
   const WorkItem it = items[item];
   const u32 tid = threadIdx.x;
   Ctx c;
   stamp(it, 0);
-  const ProgramHeader hdr = load_program<kBlockThreads, 0>(it, item, programs, status, c);
+  const ProgramHeader hdr = load_program<kBlockThreads, 0>(it, entry, programs, status, c);
   stamp(it, 1);
 
   // bit-unpack indexes: one stream per wave, streams in parallel
@@ -3330,48 +3336,48 @@ __device__ __forceinline__ void decode_block(const WorkItem* __restrict__ items,
 // `order` lists the work items this launch decodes (integer and double columns are launched
 // separately); status words are indexed by work item.
 extern "C" __global__ void __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(6, 8)))
-btr_decode_int_kernel(const WorkItem* __restrict__ items, const u32* __restrict__ order,
+btr_decode_int_kernel(const WorkItem* __restrict__ items, const LaunchEntry* __restrict__ order,
                       const u8* __restrict__ programs, u32* __restrict__ status) {
   decode_block<false, false>(items, order, programs, status);
 }
 
 // 128 VGPRs (four waves per SIMD): at 96 the kernel spilled 38 registers.
 extern "C" __global__ void __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(4, 8)))
-btr_decode_dbl_kernel(const WorkItem* __restrict__ items, const u32* __restrict__ order,
+btr_decode_dbl_kernel(const WorkItem* __restrict__ items, const LaunchEntry* __restrict__ order,
                       const u8* __restrict__ programs, u32* __restrict__ status) {
   decode_block<true, false>(items, order, programs, status);
 }
 
 // Streamed bit-packed integer roots, one kernel per post-op signature (plan.h: KERNEL_STREAM_*).
 extern "C" __global__ void __launch_bounds__(kStreamThreads)
-btr_stream_none_kernel(const WorkItem* __restrict__ items, const u32* __restrict__ order,
+btr_stream_none_kernel(const WorkItem* __restrict__ items, const LaunchEntry* __restrict__ order,
                        const u8* __restrict__ programs, u32* __restrict__ status) {
   stream_block<PS_NONE, false>(items, order, programs, status);
 }
 extern "C" __global__ void __launch_bounds__(kStreamThreads)
-btr_stream_add_kernel(const WorkItem* __restrict__ items, const u32* __restrict__ order,
+btr_stream_add_kernel(const WorkItem* __restrict__ items, const LaunchEntry* __restrict__ order,
                       const u8* __restrict__ programs, u32* __restrict__ status) {
   stream_block<PS_ADD, false>(items, order, programs, status);
 }
 extern "C" __global__ void __launch_bounds__(kStreamThreads)
-btr_stream_dict_lds_kernel(const WorkItem* __restrict__ items, const u32* __restrict__ order,
+btr_stream_dict_lds_kernel(const WorkItem* __restrict__ items, const LaunchEntry* __restrict__ order,
                            const u8* __restrict__ programs, u32* __restrict__ status) {
   stream_block<PS_DICT_LDS, false>(items, order, programs, status);
 }
 extern "C" __global__ void __launch_bounds__(kStreamThreads)
-btr_stream_dict_glb_kernel(const WorkItem* __restrict__ items, const u32* __restrict__ order,
+btr_stream_dict_glb_kernel(const WorkItem* __restrict__ items, const LaunchEntry* __restrict__ order,
                            const u8* __restrict__ programs, u32* __restrict__ status) {
   stream_block<PS_DICT_GLB, false>(items, order, programs, status);
 }
 // PSEUDODECIMAL(BP, BP, raw patches) double columns (plan.h: KERNEL_STREAM_PSEUDO).
 extern "C" __global__ void __launch_bounds__(kStreamThreads) __attribute__((amdgpu_waves_per_eu(8, 8)))
-btr_stream_pseudo_kernel(const WorkItem* __restrict__ items, const u32* __restrict__ order,
+btr_stream_pseudo_kernel(const WorkItem* __restrict__ items, const LaunchEntry* __restrict__ order,
                          const u8* __restrict__ programs, u32* __restrict__ status) {
   stream_pseudo_block<false>(items, order, programs, status);
 }
 // DICT(BP) double columns (plan.h: KERNEL_STREAM_DICTD).
 extern "C" __global__ void __launch_bounds__(kDictdThreads) __attribute__((amdgpu_waves_per_eu(8, 8)))
-btr_stream_dictd_kernel(const WorkItem* __restrict__ items, const u32* __restrict__ order,
+btr_stream_dictd_kernel(const WorkItem* __restrict__ items, const LaunchEntry* __restrict__ order,
                         const u8* __restrict__ programs, u32* __restrict__ status) {
   stream_dictd_block<false>(items, order, programs, status);
 }
@@ -3380,13 +3386,13 @@ btr_stream_dictd_kernel(const WorkItem* __restrict__ items, const u32* __restric
 // 128 VGPRs (four waves per SIMD): at 96 the integer kernel spilled 35 registers, and the spill
 // stores were 14 % of the launch's write requests.
 extern "C" __global__ void __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(4, 8)))
-btr_decode_int_pfor_kernel(const WorkItem* __restrict__ items, const u32* __restrict__ order,
+btr_decode_int_pfor_kernel(const WorkItem* __restrict__ items, const LaunchEntry* __restrict__ order,
                            const u8* __restrict__ programs, u32* __restrict__ status) {
   decode_block<false, true>(items, order, programs, status);
 }
 
 extern "C" __global__ void __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(4, 8)))
-btr_decode_dbl_pfor_kernel(const WorkItem* __restrict__ items, const u32* __restrict__ order,
+btr_decode_dbl_pfor_kernel(const WorkItem* __restrict__ items, const LaunchEntry* __restrict__ order,
                            const u8* __restrict__ programs, u32* __restrict__ status) {
   decode_block<true, true>(items, order, programs, status);
 }
@@ -3394,7 +3400,7 @@ btr_decode_dbl_pfor_kernel(const WorkItem* __restrict__ items, const u32* __rest
 // The stream kernels with the nullmap steps behind the root (plan.h: stream kind + KERNEL_STREAM_NULLMAP).
 #define BTR_STREAM_NULLMAP_KERNEL(name, threads, body)                                                     \
   extern "C" __global__ void __launch_bounds__(threads) __attribute__((amdgpu_waves_per_eu(8, 8)))         \
-  name(const WorkItem* __restrict__ items, const u32* __restrict__ order, const u8* __restrict__ programs, \
+  name(const WorkItem* __restrict__ items, const LaunchEntry* __restrict__ order, const u8* __restrict__ programs, \
        u32* __restrict__ status) {                                                                          \
     body(items, order, programs, status);                                                                   \
   }

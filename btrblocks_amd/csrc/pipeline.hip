@@ -225,7 +225,7 @@ btr_status btr_gpu_pipeline_submit(btr_gpu_pipeline* p, const btr_part_job* job)
     return fail(BTR_ERR_OUT_OF_MEMORY, "out of host memory while compiling the plan");
   }
   const size_t order_off = round256(count * sizeof(WorkItem));
-  const size_t status_off = order_off + round256((size_t)count * 4);
+  const size_t status_off = order_off + round256((size_t)count * sizeof(LaunchEntry));
   const size_t prog_off = status_off + round256((size_t)count * 4);
   const size_t tables_off = prog_off + round256(lo.blob.size() + 16);
   if ((st = grow_device(s.d_arena, s.d_arena_cap, tables_off + lo.scratch)) != BTR_OK) return st;
@@ -237,7 +237,7 @@ btr_status btr_gpu_pipeline_submit(btr_gpu_pipeline* p, const btr_part_job* job)
     items[i].debug_buf = 0;
   }
   memcpy(s.h_stage, items.data(), count * sizeof(WorkItem));
-  memcpy(s.h_stage + order_off, lo.order.data(), (size_t)count * 4);
+  memcpy(s.h_stage + order_off, lo.order.data(), (size_t)count * sizeof(LaunchEntry));
   memset(s.h_stage + status_off, 0, (size_t)count * 4);
   memcpy(s.h_stage + prog_off, lo.blob.data(), lo.blob.size());
   p->stats.compile_seconds += now_s() - t0;
@@ -249,7 +249,7 @@ btr_status btr_gpu_pipeline_submit(btr_gpu_pipeline* p, const btr_part_job* job)
   // ---- decode ----------------------------------------------------------------------------------
   HIP_TRY(hipStreamWaitEvent(p->s_dec, s.in_done, 0));
   const WorkItem* d_items = reinterpret_cast<const WorkItem*>(s.d_arena);
-  const uint32_t* d_order = reinterpret_cast<const uint32_t*>(s.d_arena + order_off);
+  const LaunchEntry* d_order = reinterpret_cast<const LaunchEntry*>(s.d_arena + order_off);
   uint32_t* d_status = reinterpret_cast<uint32_t*>(s.d_arena + status_off);
   for (uint32_t kind = 0; kind < KERNEL_KINDS; kind++) {
     const size_t cnt = lo.kind_begin[kind + 1] - lo.kind_begin[kind];

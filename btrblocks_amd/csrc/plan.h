@@ -138,6 +138,17 @@ struct WorkItem {
   uint64_t debug_buf;    // flag 8: kDebugSlots 100 MHz timestamps of this item
 };
 constexpr uint32_t kDebugSlots = 16;
+// One entry per workgroup of a launch, in launch order: which work item it decodes and where that
+// item's program lies. The program's place is repeated here so that a workgroup can start copying
+// its program as soon as it has its entry, beside the load of the work item (two dependent memory
+// round trips at the start of a block instead of three).
+struct LaunchEntry {
+  uint32_t item;
+  uint32_t prog_off;
+  uint32_t prog_bytes;
+  uint32_t pad;
+};
+static_assert(sizeof(LaunchEntry) == 16, "one 16-byte scalar load");
 // The item belongs to a small launch that runs on a side stream beside the plan's main launch: its
 // waves raise their priority, or they would crawl among the main launch's waves and end long after it.
 enum : uint32_t { ITEM_SIDE_LAUNCH = 1u << 0 };
