@@ -1517,7 +1517,7 @@ __device__ __forceinline__ void stream_int_bp(const Ctx& c, const Pipe& p, const
   sp.dict_off = e.post_tab[0].lds;
   sp.dict_g = make_rsrc(PS == PS_DICT_GLB ? e.post_tab[0].g : e.bp.base, PS == PS_DICT_GLB ? sp.n * 4 : 0);
   u32 code_max = 0;
-  ring_pass(
+  ring_pass<false, kStreamWaves, 0, false, true>(  // first batches issued by the caller
       c, p, e.bp, jump_off, [](const ChainState& st) { return st.g; },
       [&](u32 g_lo, u32 g_hi, u32 uw) { ring_eval_groups<PS>(sp, u, dst_rsrc, e.bp.index_off, g_lo, g_hi, uw, code_max); });
   if ((PS == PS_DICT_LDS || PS == PS_DICT_GLB) && code_max >= sp.n) raise(c, ST_DICT_CODE);
@@ -1544,7 +1544,7 @@ __device__ __forceinline__ void stream_dictd(const Ctx& c, const Pipe& root, u64
     code = code < dict.count ? code : dict.count - 1;
     return in_lds ? lds64(dict.lds + 8 * code) : ldg64(dict.g + 8ull * code);
   };
-  ring_pass<false, kDictdWaves>(
+  ring_pass<false, kDictdWaves, 0, false, true>(  // first batches issued by the caller
       c, pc, bp, jump_off, [](const ChainState& st) { return st.g; },
       [&](u32 g_lo, u32 g_hi, u32 uw) {
         for (u32 g = g_lo + uw; g < g_hi; g += kDictdWaves - 2) {
@@ -3189,6 +3189,12 @@ __device__ __forceinline__ void stream_block(const WorkItem* __restrict__ items,
   Ctx c;
   const ProgramHeader hdr = load_program<kStreamThreads, kStreamProgBase>(it, entry, programs, status, c);
   const u32 root_idx = NM ? stream_root_index(c, hdr) : hdr.n_steps - 1;
+  const Step& root = step_at(c, root_idx);
+  const u32 pipe_id = uniform(root.a[0]);
+  const IntEval e = resolve_int(c, pipe_id);
+  // the loading wave starts the first batches of the payload before the dictionary is copied: the two
+  // memory latencies overlap (the ring lies in front of everything else in LDS)
+  if (uniform(threadIdx.x >> 6) == kStreamWaves - 1) ring_issue_first<false, false>(e.bp, pipe_at(c, pipe_id));
   for (u32 s = 0; s < root_idx; s++) {  // dictionary copies: a bare source sequence -> LDS
     const Step& st = step_at(c, s);
     const Tab from = resolve_tab(c, uniform(pipe_at(c, uniform(st.a[0])).a[0]));
@@ -3196,9 +3202,6 @@ __device__ __forceinline__ void stream_block(const WorkItem* __restrict__ items,
     copy_to_lds<kStreamThreads>(to.lds, from.g, to.count * to.esize);
   }
   __syncthreads();
-  const Step& root = step_at(c, root_idx);
-  const u32 pipe_id = uniform(root.a[0]);
-  const IntEval e = resolve_int(c, pipe_id);
   stream_int_bp<PS>(c, pipe_at(c, pipe_id), e, reinterpret_cast<u32*>(c.dst), jump_scratch(c, root));
   if (NM) stream_trailing_nullmap<kStreamThreads>(c, hdr, root_idx);
 }
@@ -3214,6 +3217,11 @@ __device__ __forceinline__ void stream_dictd_block(const WorkItem* __restrict__ 
   stamp(it, 0);
   const ProgramHeader hdr = load_program<kDictdThreads, kStreamProgBase>(it, entry, programs, status, c);
   const u32 root_idx = NM ? stream_root_index(c, hdr) : hdr.n_steps - 1;
+  const Step& root = step_at(c, root_idx);
+  if (uniform(threadIdx.x >> 6) == kDictdWaves - 1) {  // first payload batches beside the dictionary copy
+    const Pipe& codes = pipe_at(c, uniform(pipe_at(c, uniform(root.a[0])).a[0]));
+    ring_issue_first<false, false>(resolve_bp(c, codes), codes);
+  }
   for (u32 s = 0; s < root_idx; s++) {
     const Step& st = step_at(c, s);
     const Tab from = resolve_tab(c, uniform(pipe_at(c, uniform(st.a[0])).a[0]));
@@ -3222,7 +3230,6 @@ __device__ __forceinline__ void stream_dictd_block(const WorkItem* __restrict__ 
   }
   __syncthreads();
   stamp(it, 1);
-  const Step& root = step_at(c, root_idx);
   stream_dictd(c, pipe_at(c, uniform(root.a[0])), reinterpret_cast<u64*>(c.dst), jump_scratch(c, root));
   if (NM) stream_trailing_nullmap<kDictdThreads>(c, hdr, root_idx);
   stamp(it, 2);
