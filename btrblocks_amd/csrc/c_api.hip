@@ -434,6 +434,9 @@ btr_status finish_plan(btr_gpu_ctx* ctx, std::vector<WorkItem>& items, std::vect
     if ((e = hipMemcpy(plan->d_order, lo.order.data(), lo.order.size() * sizeof(LaunchEntry), hipMemcpyHostToDevice)) != hipSuccess)
       return cleanup(hip_fail(e, "hipMemcpy(order)"));
   }
+  // The status words are cleared by a memset that the host does not wait for. A decode on a stream
+  // that does not order itself behind the default stream must still find the plan complete.
+  if ((e = hipStreamSynchronize(nullptr)) != hipSuccess) return cleanup(hip_fail(e, "hipStreamSynchronize"));
   stats.upload_seconds = now_s() - t_start;
   plan->stats = stats;
   *out = plan;
