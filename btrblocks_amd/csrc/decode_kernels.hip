@@ -2068,51 +2068,44 @@ __device__ __forceinline__ void mat_dbl2(const Ctx& c, const DblEval& e, u64* __
   if (tid < count - pairs) dst[pairs + tid] = eval_dbl<BASE, GEN, GEN, PS_GEN>(e, pairs + tid, bad);
 }
 
-// PSEUDODECIMAL whose digits and exponents are both run-length encoded (bare RLE pipes). A lane
-// evaluates two row pairs of one 64-row bitmap word, rows 2j, 2j+1 and 32+2j, 33+2j for j = lane % 16:
-// the four rows share the word of the exponents' run starts and the word of the exception flags
-// (one read of each, one rank lookup each, the rest is bit counting). Before the stores the lanes of a
-// wave exchange their pairs so that a store instruction writes 1 KiB without a gap: 16 bytes per lane
-// at a stride of 32 reach the memory system as half-size write requests. Results are those of eval_dbl<B_PSEUDO> row by
-// row (double/Pseudodecimal.cpp:424-436).
+// PSEUDODECIMAL whose digits and exponents are both run-length encoded (bare RLE pipes), four
+// consecutive rows per lane: the rows share one word of each bitmap (run starts of the exponents,
+// exception flags, and - up to a word boundary - run starts of the digits), so each of the three
+// rank lookups is made once and advanced by flag bits for the other rows. Results are those of
+// eval_dbl<B_PSEUDO> row by row (double/Pseudodecimal.cpp:424-436).
 // EXP_LDS / DIG_LDS: where the run-value tables sit, fixed at compile time so that a lane's loads
 // are not separated by location tests.
 template <bool EXP_LDS, bool DIG_LDS>
 __device__ __forceinline__ void mat_pseudo_rle4(const Ctx& c, const DblEval& e, u64* __restrict__ dst, u32 count) {
   const u32 tid = threadIdx.x;
-  const u32 pairs = count & ~1u;  // rows that are stored as pairs (the output is 16-byte aligned)
-  const u32 last_word = (pairs - 1) >> 6;
-  const u32 units = (last_word + 1) * 16;  // a unit: one lane's four rows
+  const u32 quads = count & ~3u;
   u32 bad = 0;
   const u32 e_last = e.ib.tab.count - 1, d_last = e.k0 ? e.ia.tab.count - 1 : 0;
   const u32 di_last = e.k0 ? e.k0 - 1 : 0;
   const bool patches_lds = e.tab.loc == LOC_LDS;
   const __amdgpu_buffer_rsrc_t rsrc_p = make_rsrc(patches_lds ? nullptr : e.tab.g, patches_lds ? 0 : e.tab.count * 8);
-  // two units per lane and iteration: the table loads of both (the digit values may sit in the
+  // two quads per lane and iteration: the table loads of both (the digit values may sit in the
   // chunk's scratch slice in global memory) are in flight together
-  auto unit = [&](u32 u, u64 (&out)[4]) {
-    const u32 wu = u >> 4;
-    const u32 w = wu < last_word ? wu : last_word;  // lanes past the end repeat the last word
-    const u32 p0 = 2 * (u & 15), p1 = p0 + 32;
-    const u32 i0 = 64 * w + p0;
-    // exponents: run index of a row = starts at or before it, minus one
+  auto quad = [&](u32 first, u64 (&out)[4]) -> u32 {
+    const u32 i = first < quads ? first : quads - 4;  // lanes past the end repeat the last quad
+    const u32 w = i >> 6, p = i & 63;
+    // exponents: run index of row i + k = starts at or before it, minus one
     const u64 se = lds64(e.ib.rk.bits_off + 8 * w);
-    const u32 re = lds32(e.ib.rk.rank_off + 4 * w);
-    // exceptions strictly before a row
+    const u32 ne = lds32(e.ib.rk.rank_off + 4 * w) + (u32)__popcll(se & ((2ull << p) - 1));
+    const u32 fe = (u32)((se >> p) >> 1);  // start flags of rows i+1..
+    // exceptions strictly before row i + k
     const u64 sx = lds64(e.rk.bits_off + 8 * w);
-    const u32 rx = lds32(e.rk.rank_off + 4 * w);
-    const u32 ne0 = re + (u32)__popcll(se & ((2ull << p0) - 1)), ne1 = re + (u32)__popcll(se & ((2ull << p1) - 1));
-    const u32 nx0 = rx + (u32)__popcll(sx & ((1ull << p0) - 1)), nx1 = rx + (u32)__popcll(sx & ((1ull << p1) - 1));
-    const u32 n[4] = {ne0, ne0 + ((u32)(se >> (p0 + 1)) & 1), ne1, ne1 + ((u32)(se >> (p1 + 1)) & 1)};
-    const u32 xr[4] = {nx0, nx0 + ((u32)(sx >> p0) & 1), nx1, nx1 + ((u32)(sx >> p1) & 1)};
-    const u32 row[4] = {i0, i0 + 1, i0 + 32, i0 + 33};
-    u32 ex[4], di[4];
+    const u32 nx = lds32(e.rk.rank_off + 4 * w) + (u32)__popcll(sx & ((1ull << p) - 1));
+    const u32 fx = (u32)(sx >> p) & 15;
+    u32 ex[4], xr[4], di[4];
 #pragma unroll
     for (u32 k = 0; k < 4; k++) {
-      u32 r = n[k] ? n[k] - 1 : 0;
+      const u32 n = ne + (u32)__builtin_popcount(fe & ((1u << k) - 1));
+      u32 r = n ? n - 1 : 0;
       r = r < e_last ? r : e_last;
       ex[k] = EXP_LDS ? lds32(e.ib.tab.lds + 4 * r) : ldg32(e.ib.tab.g + 4ull * r);
-      const u32 d = row[k] - xr[k];
+      xr[k] = nx + (u32)__builtin_popcount(fx & ((1u << k) - 1));
+      const u32 d = i + k - xr[k];
       di[k] = d < di_last ? d : di_last;
     }
     // patch candidates for all four rows, loaded before anything waits for them (an index past the
@@ -2128,19 +2121,18 @@ __device__ __forceinline__ void mat_pseudo_rle4(const Ctx& c, const DblEval& e, 
         pw[k] = ((u64)t.y << 32) | t.x;
       }
     }
-    // digits: rank lookup for the first digit index; the other three are at most 33 digits further on,
-    // inside the 64 start flags that follow it
+    // digits: rank lookup for the first digit index, flag bits for the (at most three) following ones
     u32 dg[4] = {0, 0, 0, 0};
     if (e.k0) {
       const u32 wd = di[0] >> 6, pd = di[0] & 63;
       const u64 s0 = lds64(e.ia.rk.bits_off + 8 * wd), s1 = lds64(e.ia.rk.bits_off + 8 * wd + 8);
       const u32 nd = lds32(e.ia.rk.rank_off + 4 * wd) + (u32)__popcll(s0 & ((2ull << pd) - 1));
-      const u64 fd = ((s0 >> pd) >> 1) | ((s1 << (63 - pd)));  // start flags of digits di[0]+1..
+      const u32 fd = (u32)(((s0 >> pd) >> 1) | ((s1 << (63 - pd))));  // start flags of digits di[0]+1..
 #pragma unroll
       for (u32 k = 0; k < 4; k++) {
-        const u32 ahead = di[k] - di[0];  // 0..33
-        const u32 nk = nd + (u32)__popcll(fd & ((1ull << ahead) - 1));
-        u32 r = nk ? nk - 1 : 0;
+        const u32 ahead = di[k] - di[0];  // 0..3
+        const u32 n = nd + (u32)__builtin_popcount(fd & ((1u << ahead) - 1));
+        u32 r = n ? n - 1 : 0;
         r = r < d_last ? r : d_last;
         dg[k] = DIG_LDS ? lds32(e.ia.tab.lds + 4 * r) : ldg32(e.ia.tab.g + 4ull * r);
       }
@@ -2155,40 +2147,28 @@ __device__ __forceinline__ void mat_pseudo_rle4(const Ctx& c, const DblEval& e, 
       out[k] = (u64)__double_as_longlong((double)(int)dg[k] * __longlong_as_double((long long)fbits));
       if (ex[k] == btrfmt::DEC_EXCEPTION_CODE) out[k] = pw[k];
     }
+    return i;
   };
-  // The lanes of a wave hold rows [0,32) of four words in `a` and rows [32,64) in `b`, sixteen lanes
-  // per word. Two swaps of 16-lane rows between the two registers leave rows 2t, 2t+1 of the wave's
-  // 256-row span in lane t of the first and rows 128+2t, 129+2t in the second: each store
-  // instruction then writes 1 KiB without a gap.
-  auto put = [&](u32 span, const u64 (&out)[4]) {
-    u32 a[4] = {(u32)out[0], (u32)(out[0] >> 32), (u32)out[1], (u32)(out[1] >> 32)};
-    u32 b[4] = {(u32)out[2], (u32)(out[2] >> 32), (u32)out[3], (u32)(out[3] >> 32)};
-#pragma unroll
-    for (u32 d = 0; d < 4; d++) {
-      const auto r = __builtin_amdgcn_permlane16_swap(a[d], b[d], false, false);  // words 0|0|2|2 and 1|1|3|3
-      const auto q = __builtin_amdgcn_permlane32_swap(r[0], r[1], false, false);  // words 0|0|1|1 and 2|2|3|3
-      a[d] = q[0], b[d] = q[1];
+  auto put = [&](u32 first, u32 i, const u64 (&out)[4]) {
+    if (first < quads) {
+      u64x2 lo, hi;
+      lo.x = out[0], lo.y = out[1], hi.x = out[2], hi.y = out[3];
+      __builtin_nontemporal_store(lo, reinterpret_cast<u64x2*>(dst + i));
+      __builtin_nontemporal_store(hi, reinterpret_cast<u64x2*>(dst + i + 2));
     }
-    u64x2 lo, hi;
-    lo.x = ((u64)a[1] << 32) | a[0], lo.y = ((u64)a[3] << 32) | a[2];
-    hi.x = ((u64)b[1] << 32) | b[0], hi.y = ((u64)b[3] << 32) | b[2];
-    const u32 i = span + 2 * (tid & 63);
-    if (i + 2 <= pairs) __builtin_nontemporal_store(lo, reinterpret_cast<u64x2*>(dst + i));
-    if (i + 130 <= pairs) __builtin_nontemporal_store(hi, reinterpret_cast<u64x2*>(dst + i + 128));
   };
-  for (u32 base = 0; base < units; base += kBlockThreads * 2) {
+  for (u32 base = 0; base < quads; base += kBlockThreads * 8) {
     u64 oa[4], ob[4];
-    unit(base + tid, oa);
-    unit(base + tid + kBlockThreads, ob);
-    const u32 span = 4 * (base + (tid & ~63u));  // first row of the wave's first unit
-    put(span, oa);
-    put(span + 4 * kBlockThreads, ob);
+    const u32 fa = base + tid * 4, fb = fa + kBlockThreads * 4;
+    const u32 ia = quad(fa, oa), ib = quad(fb, ob);
+    put(fa, ia, oa);
+    put(fb, ib, ob);
   }
   {
-    // an odd last row; every lane evaluates (the powers of ten are fetched by lane permute, which
-    // reads from active lanes only), the first stores
-    const u64 v = eval_dbl<B_PSEUDO, B_RLE, B_RLE, PS_NONE>(e, pairs + tid < count ? pairs + tid : count - 1, bad);
-    if (tid < count - pairs) dst[pairs + tid] = v;
+    // the last count % 4 rows; every lane evaluates (the powers of ten are fetched by lane permute,
+    // which reads from active lanes only), the first few store
+    const u64 v = eval_dbl<B_PSEUDO, B_RLE, B_RLE, PS_NONE>(e, quads + tid < count ? quads + tid : count - 1, bad);
+    if (tid < count - quads) dst[quads + tid] = v;
   }
   report(c, bad);
 }
