@@ -9,6 +9,6 @@ for v in product $VARIANTS; do
   python - <<PY
 import json
 l=[x for x in open("gpurun_out/rel_$v.log") if x.startswith("{")]
-d=json.loads(l[-1]); print("$v", d["value"], d["ms_per_step"], {k:v["kernel_ms"] for k,v in d["roofline"]["per_column"].items() if k in ("pseudodecimal","pseudo_rle","dbl_rle")})
+d=json.loads(l[-1]); print("$v", d["value"], d["ms_per_step"], {k:v["kernel_ms"] for k,v in d["roofline"]["per_column"].items()})
 PY
 done
