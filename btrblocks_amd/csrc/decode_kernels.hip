@@ -3276,10 +3276,25 @@ __device__ __forceinline__ void stream_pseudo_block(const WorkItem* __restrict__
       lds_st64(frac_off + 8 * threadIdx.x,
                (u64)__double_as_longlong(kFractions[ev < btrfmt::DEC_MAX_EXPONENT ? ev : btrfmt::DEC_MAX_EXPONENT]));
   }
+  // The patches are gathered row by row during the digit pass: their lines are pulled into L2 now, one
+  // load per 128-byte line with the value unused, so that the gathers do not go to HBM one by one.
+  u32 warm = 0;
+  {
+    const Tab pt = resolve_tab(c, uniform(rp.a[2]));
+    const u32 lines = (pt.count * 8 + 127) / 128;
+    if (pt.loc != LOC_LDS && pt.count && lines <= kStreamThreads) {
+      const u64 first = reinterpret_cast<u64>(pt.g) & ~3ull, last = (reinterpret_cast<u64>(pt.g) + pt.count * 8 - 4) & ~3ull;
+      if (threadIdx.x < lines) {
+        const u64 a = first + 128ull * threadIdx.x;
+        warm = ldg32(reinterpret_cast<const u8*>(a < last ? a : last));
+      }
+    }
+  }
   bitmap_clear<kStreamThreads>(c, step_at(c, root_idx - 2));
   __syncthreads();
   stamp(it, 2);
   stream_exception_bits(c, pe, resolve_bp(c, pe), rk, n / 64 + 1, n, jump_off, xc);
+  asm volatile("" ::"v"(warm));  // keeps the loads above
   stamp(it, 3);
   // the exponent pass ended with a barrier and nothing reads the ring until the digit pass: its
   // loading wave starts the first digit batches now, so that they land while the ranks are built
