@@ -313,22 +313,40 @@ class DecodePlan:
         self.close()
 
 
+class _PinnedMemory:
+    """One btr_host_alloc allocation; freed when the last reference goes away."""
+
+    def __init__(self, lib, nbytes):
+        self.lib = lib
+        p = C.c_void_p()
+        N.check(lib.btr_host_alloc(max(int(nbytes), 1), C.byref(p)))
+        self.ptr = p.value
+
+    def __del__(self):
+        if getattr(self, "ptr", None):
+            self.lib.btr_host_free(C.c_void_p(self.ptr))
+            self.ptr = None
+
+
 class PinnedBuffer:
-    """Pinned host memory (btr_host_alloc) seen as a uint8 numpy array."""
+    """Pinned host memory (btr_host_alloc) seen as a uint8 numpy array. The memory belongs to
+    `array` and to every view taken from it: it is freed when the PinnedBuffer and all of those
+    arrays are gone, so a column returned as a view stays valid for as long as the caller holds it."""
 
     def __init__(self, nbytes):
         self.lib = N.load()
-        p = C.c_void_p()
-        N.check(self.lib.btr_host_alloc(max(int(nbytes), 1), C.byref(p)))
-        self.ptr = p.value
+        self._mem = _PinnedMemory(self.lib, nbytes)
+        self.ptr = self._mem.ptr
         self.nbytes = int(nbytes)
-        self.array = np.ctypeslib.as_array((C.c_uint8 * max(self.nbytes, 1)).from_address(self.ptr))[:self.nbytes]
+        raw = (C.c_uint8 * max(self.nbytes, 1)).from_address(self.ptr)
+        raw._owner = self._mem  # numpy keeps `raw` as the base of the array and of its views
+        self.array = np.ctypeslib.as_array(raw)[:self.nbytes]
 
     def close(self):
-        if getattr(self, "ptr", None):
-            self.array = None
-            self.lib.btr_host_free(C.c_void_p(self.ptr))
-            self.ptr = None
+        """Drops this object's references; the memory itself goes with the last view of `array`."""
+        self.array = None
+        self._mem = None
+        self.ptr = None
 
     def __del__(self):
         self.close()

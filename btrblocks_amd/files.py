@@ -124,8 +124,9 @@ class BtrDirectory:
         return sizes
 
     def decode_column(self, column, with_nullmap=False, out=None):
-        """Streams every part of a column through the GPU. Returns the column as a host array (a
-        view of pinned memory unless `out`, an api.PinnedBuffer, is given); with_nullmap adds the
+        """Streams every part of a column through the GPU. Returns the column as a host array: a
+        view of pinned memory (a new allocation per call, or `out`, an api.PinnedBuffer) that keeps
+        that memory alive for as long as the array or any view of it exists; with_nullmap adds the
         byte-per-row validity array."""
         ctype = self.columns[column][0]
         dtype = np.float64 if ctype == 1 else np.int32
@@ -150,7 +151,6 @@ class BtrDirectory:
                                  host_nullmap=(nm.ptr + row_at) if nm else None, nullmap_bytes=rows if nm else 0)
             row_at += rows
         self.pipeline.drain()
-        self._keep = (out, nm)
         # Chunk starts are 16-byte aligned; full 64k-row blocks leave no gaps, so the usual column is
         # one contiguous view. Only a ragged block in the middle of a column needs the pieces joined.
         pieces = [(s + o, n) for s, (_, _, _, ps) in zip(starts, sizes) for o, n in ps]

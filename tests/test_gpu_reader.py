@@ -18,7 +18,10 @@ def _bits(a):
 
 @pytest.mark.parametrize("gen,spec", [("int_rle", "rle(bp,bp)"), ("int_dict", "dict(bp)"), ("int_for", "for(bp)"),
                                       ("double_decimal", "pseudodecimal(bp,bp,uncompressed)"),
-                                      ("int_dict", "auto"), ("double_decimal", "auto")])
+                                      ("int_dict", "auto"), ("double_decimal", "auto"),
+                                      # tools/examples/compression.cpp:10-20 at 1 000 000 rows: mt19937(42) % 4095 in
+                                      # runs of 40, default scheme set
+                                      ("example_runs", "auto")])
 def test_reader_decodes_whole_column(gpu_ctx, gen, spec):
     rows = 1_000_000  # 16 blocks: 15 full + 16960 rows
     values = getattr(synth, gen)(rows)
@@ -240,6 +243,16 @@ def test_relation_directory_round_trip(gpu_ctx, tmp_path):
     for c, want in enumerate(cols):
         got = d.decode_column(c)
         assert np.array_equal(got.view(np.uint8), want.view(np.uint8))
+    # every column held at once, compared after the last decode and after the directory object is
+    # gone: a returned array owns the pinned memory it views
+    held = [d.decode_column(c) for c in range(len(cols))]
+    held_nm = [d.decode_column(c, with_nullmap=True)[1] for c in range(len(cols))]
+    del d
+    import gc
+    gc.collect()
+    for got, nm, want in zip(held, held_nm, cols):
+        assert np.array_equal(got.view(np.uint8), want.view(np.uint8))
+        assert nm.shape == (rows,) and bool(nm.all())
 
 
 @pytest.mark.gpu

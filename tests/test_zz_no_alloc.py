@@ -9,6 +9,7 @@ import pytest
 import btrblocks_amd as B
 from btrblocks_amd import _native as N
 from btrblocks_amd import api, synth
+from oracle import pyoracle
 
 pytestmark = pytest.mark.gpu
 
@@ -57,7 +58,14 @@ def _decode_both(ctx, chunks, want_nullmap):
         assert torch.equal(ma, mb), f"chunk {k}: nullmap differs from the planned decode"
         assert bool((b[int(infos[k].decoded_bytes):] == 0xA5).all())
     plan.close()
-    return [o[:int(i.decoded_bytes)].cpu().numpy() for o, i in zip(outs_b, infos)]
+    got = [o[:int(i.decoded_bytes)].cpu().numpy() for o, i in zip(outs_b, infos)]
+    # ... and against the CPU oracle, every row (null or not) and the byte-per-row nullmap
+    for k, (c, g, i) in enumerate(zip(chunks, got, infos)):
+        want, want_nm = pyoracle.decode_chunk(c, want_nullmap=True)
+        assert np.array_equal(g, want.view(np.uint8)), f"chunk {k}: column differs from the oracle"
+        if want_nullmap:
+            assert np.array_equal(nms_b[k][:i.tuple_count].cpu().numpy(), want_nm), f"chunk {k}: nullmap differs from the oracle"
+    return got
 
 
 def test_noalloc_matches_planned_decode_twice(gpu_ctx):
