@@ -322,9 +322,9 @@ class _PinnedMemory:
         N.check(lib.btr_host_alloc(max(int(nbytes), 1), C.byref(p)))
         self.ptr = p.value
 
-    def __del__(self):
+    def __del__(self, _void_p=C.c_void_p):  # bound early: module globals may be gone at interpreter exit
         if getattr(self, "ptr", None):
-            self.lib.btr_host_free(C.c_void_p(self.ptr))
+            self.lib.btr_host_free(_void_p(self.ptr))
             self.ptr = None
 
 

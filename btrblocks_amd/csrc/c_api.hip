@@ -146,29 +146,40 @@ StaticArea g_static_area[kMaxDevices];
 std::mutex g_static_mutex;
 }  // namespace
 
-constexpr uint32_t kColumnLanes = 8;  // streams btr_gpu_decode_columns spreads plans over
+// Every stream the library uses besides the caller's lives in the context, created with it and
+// destroyed with it. Plans and pipelines borrow them: nothing on the decode path creates or destroys
+// a stream. All of them are plain non-blocking streams, which HIP multiplexes onto the process's
+// hardware queues (four by default). They are never streams with a raised priority: such a stream
+// gets a hardware queue of its own beyond those four, and a launch on the caller's stream that
+// waits for an event of that queue was seen to never start once the other queues were in use (a
+// plan of several kernel kinds decoded right behind other plans; the device then never went idle).
+constexpr uint32_t kColumnLanes = 3;   // with the caller's stream: four launches beside each other
+constexpr uint32_t kPipeStreams = 3;   // copy-in, decode and copy-out streams of the part pipelines
 
 struct btr_gpu_ctx {
   int device = 0;
   StaticArea* area = nullptr;
-  // btr_gpu_decode_columns: a few non-blocking streams that fork from and join the caller's stream,
-  // created with the context so that the decode call itself allocates nothing. Calls on one
-  // context enqueue under the mutex (the events are reused from call to call).
-  std::mutex lanes_mutex;
+  // Calls that enqueue on the context's streams do so under this mutex (the join events are reused
+  // from call to call: a wait captures the record that precedes it on the host).
+  std::recursive_mutex streams_mutex;
   hipStream_t lane[kColumnLanes] = {};
   hipEvent_t lane_done[kColumnLanes] = {};
   hipEvent_t lanes_fork = nullptr;
+  hipStream_t pipe[kPipeStreams] = {};
+  uint32_t next_side = 0;
   ~btr_gpu_ctx() {
-    if (!lanes_fork) return;
     DeviceGuard guard(device);
-    for (uint32_t k = 0; k < kColumnLanes; k++) {
-      if (lane[k]) {
-        (void)hipStreamSynchronize(lane[k]);
-        (void)hipStreamDestroy(lane[k]);
-      }
-      if (lane_done[k]) (void)hipEventDestroy(lane_done[k]);
-    }
-    (void)hipEventDestroy(lanes_fork);
+    auto drop = [](hipStream_t& s) {
+      if (!s) return;
+      (void)hipStreamSynchronize(s);
+      (void)hipStreamDestroy(s);
+      s = nullptr;
+    };
+    for (hipStream_t& s : lane) drop(s);
+    for (hipStream_t& s : pipe) drop(s);
+    for (hipEvent_t& e : lane_done)
+      if (e) (void)hipEventDestroy(e);
+    if (lanes_fork) (void)hipEventDestroy(lanes_fork);
   }
 };
 
@@ -177,20 +188,24 @@ struct btr_gpu_plan {
   size_t n_items = 0;
   WorkItem* d_items = nullptr;
   uint8_t* d_programs = nullptr;
+  size_t program_bytes = 0;
   uint32_t* d_status = nullptr;
   LaunchEntry* d_order = nullptr;  // launch entries (work item index, program place) grouped by the kernel that decodes them
   size_t kind_begin[KERNEL_KINDS + 1] = {};
   uint32_t kind_lds[KERNEL_KINDS] = {};  // dynamic LDS per launch
   uint8_t* d_scratch = nullptr;
   uint32_t* d_debug = nullptr;  // BTR_DEBUG_FLAGS & 8: kDebugSlots timestamps per work item
-  // A plan with several kernel kinds launches all but the largest on side streams (created with the
-  // plan) that fork from and join the caller's stream by events: a handful of odd chunks then
-  // decode beside the main launch instead of adding their whole latency behind it.
-  hipStream_t side[KERNEL_KINDS] = {};
+  // A plan with several kernel kinds launches all but the first of `launch_order` on lanes of the
+  // context, which fork from and join the caller's stream by the plan's events: a handful of odd
+  // chunks then decode beside the main launch instead of adding their whole latency behind it.
+  bool is_side[KERNEL_KINDS] = {};
   hipEvent_t side_done[KERNEL_KINDS] = {};
   hipEvent_t side_go[KERNEL_KINDS] = {};  // recorded on a side stream right before its launch: the main launch waits for it
   hipEvent_t fork = nullptr;
   uint32_t main_kind = 0;
+  uint32_t launch_order[KERNEL_KINDS] = {};  // kinds with chunks, the one with the most decoded bytes first
+  uint32_t n_launches = 0;
+  bool balanced = false;  // several large launches (a relation-level plan): no small odd launches to favour
   btr_plan_stats stats{};
   std::vector<uint32_t> h_status;
 };
@@ -205,7 +220,7 @@ double now_s() {
 // on several host threads (the first failing chunk is the one reported). Nothing thrown inside
 // escapes: a hostile header that exhausts memory is reported like any other malformed one.
 btr_status compile_chunks(const btr_chunk_desc* chunks, size_t n, std::vector<WorkItem>& items,
-                          std::vector<BuiltProgram>& progs, btr_plan_stats& stats) {
+                          std::vector<BuiltProgram>& progs, btr_plan_stats& stats, size_t max_workers = 16) {
   items.assign(n, WorkItem{});
   progs.assign(n, BuiltProgram{});
   std::vector<btr_chunk_info> infos(n);
@@ -259,7 +274,7 @@ btr_status compile_chunks(const btr_chunk_desc* chunks, size_t n, std::vector<Wo
     return BTR_OK;
   };
   const size_t hw = std::max(1u, std::thread::hardware_concurrency());
-  const size_t workers = n < 256 ? 1 : std::min<size_t>({hw, 16, n / 128});
+  const size_t workers = n < 256 || max_workers <= 1 ? 1 : std::min<size_t>({hw, max_workers, n / 128});
   std::vector<size_t> bad_at(workers, n);
   std::vector<btr_status> bad_status(workers, BTR_OK);
   std::vector<std::string> bad_text(workers);
@@ -334,7 +349,8 @@ void lay_out(std::vector<WorkItem>& items, const std::vector<BuiltProgram>& prog
     lo.kind_begin[kind] = lo.order.size();
     for (size_t i = 0; i < items.size(); i++)
       if (progs[i].kernel == kind) {
-        lo.order.push_back(LaunchEntry{(uint32_t)i, items[i].prog_off, items[i].prog_bytes, 0});
+        lo.order.push_back(LaunchEntry{(uint32_t)i, items[i].prog_off, items[i].prog_bytes,
+                                       launch_entry_check((uint32_t)i, items[i].prog_off, items[i].prog_bytes)});
         lo.kind_lds[kind] = std::max(lo.kind_lds[kind], progs[i].lds_bytes);
       }
   }
@@ -344,6 +360,11 @@ void lay_out(std::vector<WorkItem>& items, const std::vector<BuiltProgram>& prog
       stats.kernel_mask |= 1u << kind;
       stats.launches++;
     }
+}
+
+bool kind_is_double(uint32_t kind) {
+  const uint32_t k = kind >= KERNEL_STREAM_NONE + KERNEL_STREAM_NULLMAP ? kind - KERNEL_STREAM_NULLMAP : kind;
+  return k == KERNEL_GENERIC_DBL || k == KERNEL_STREAM_PSEUDO || k == KERNEL_STREAM_DICTD || k == KERNEL_PFOR_DBL;
 }
 
 // Uploads the built programs and work items of a plan.
@@ -368,17 +389,25 @@ btr_status finish_plan(btr_gpu_ctx* ctx, std::vector<WorkItem>& items, std::vect
     return st;
   };
   if (blob.size() > 0xFFFFFFF0ull) return cleanup(fail(BTR_ERR_UNSUPPORTED, "plan programs exceed 4 GiB"));
-  if (stats.launches > 1) {
-    // every kind but the one with the most chunks goes to a side stream
-    size_t most = 0;
-    uint32_t main_kind = 0;
+  // Launch order: the kind with the most decoded bytes first; it runs on the caller's stream, the
+  // others beside it on streams of the context. When the others are a few odd chunks (a column whose
+  // blocks almost all take one cascade) they are small side launches: raised wave priority, dispatched
+  // ahead of the main grid. When several kinds carry real shares of the work (a relation-level plan
+  // over many columns) the launches are simply spread over the context's lanes, longest first.
+  {
+    uint64_t weight[KERNEL_KINDS] = {};
+    for (size_t i = 0; i < items.size(); i++) weight[progs[i].kernel] += (uint64_t)items[i].tuple_count * (kind_is_double(progs[i].kernel) ? 8 : 4) + 1;
+    uint32_t n = 0;
     for (uint32_t kind = 0; kind < KERNEL_KINDS; kind++)
-      if (lo.kind_begin[kind + 1] - lo.kind_begin[kind] > most) {
-        most = lo.kind_begin[kind + 1] - lo.kind_begin[kind];
-        main_kind = kind;
-      }
-    for (size_t i = 0; i < items.size(); i++)
-      if (progs[i].kernel != main_kind) items[i].flags |= ITEM_SIDE_LAUNCH;
+      if (lo.kind_begin[kind + 1] > lo.kind_begin[kind]) plan->launch_order[n++] = kind;
+    std::stable_sort(plan->launch_order, plan->launch_order + n, [&](uint32_t a, uint32_t b) { return weight[a] > weight[b]; });
+    plan->n_launches = n;
+    plan->main_kind = n ? plan->launch_order[0] : 0;
+    plan->balanced = n > 1 && weight[plan->launch_order[1]] * 16 >= weight[plan->launch_order[0]];
+    for (uint32_t j = 1; j < n; j++) plan->is_side[plan->launch_order[j]] = true;
+    if (n > 1 && !plan->balanced)
+      for (size_t i = 0; i < items.size(); i++)
+        if (progs[i].kernel != plan->main_kind) items[i].flags |= ITEM_SIDE_LAUNCH;
   }
   hipError_t e;
   if (scratch) {
@@ -399,6 +428,7 @@ btr_status finish_plan(btr_gpu_ctx* ctx, std::vector<WorkItem>& items, std::vect
       return cleanup(hip_fail(e, "hipMalloc(items)"));
     if ((e = hipMalloc((void**)&plan->d_programs, blob.size() + 16)) != hipSuccess)
       return cleanup(hip_fail(e, "hipMalloc(programs)"));
+    plan->program_bytes = blob.size();
     if ((e = hipMalloc((void**)&plan->d_status, items.size() * 4)) != hipSuccess)
       return cleanup(hip_fail(e, "hipMalloc(status)"));
     if ((e = hipMemcpy(plan->d_items, items.data(), items.size() * sizeof(WorkItem), hipMemcpyHostToDevice)) != hipSuccess)
@@ -407,22 +437,11 @@ btr_status finish_plan(btr_gpu_ctx* ctx, std::vector<WorkItem>& items, std::vect
       return cleanup(hip_fail(e, "hipMemcpy(programs)"));
     if ((e = hipMemset(plan->d_status, 0, items.size() * 4)) != hipSuccess)
       return cleanup(hip_fail(e, "hipMemset(status)"));
-    size_t most = 0;
-    for (uint32_t kind = 0; kind < KERNEL_KINDS; kind++)
-      if (plan->kind_begin[kind + 1] - plan->kind_begin[kind] > most) {
-        most = plan->kind_begin[kind + 1] - plan->kind_begin[kind];
-        plan->main_kind = kind;
-      }
-    if (stats.launches > 1) {
+    if (plan->n_launches > 1) {
       if ((e = hipEventCreateWithFlags(&plan->fork, hipEventDisableTiming)) != hipSuccess)
         return cleanup(hip_fail(e, "hipEventCreate"));
       for (uint32_t kind = 0; kind < KERNEL_KINDS; kind++) {
-        if (kind == plan->main_kind || plan->kind_begin[kind + 1] == plan->kind_begin[kind]) continue;
-        // highest priority: the few workgroups of a side launch should not queue behind the main one
-        int least = 0, greatest = 0;
-        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-        if ((e = hipStreamCreateWithPriority(&plan->side[kind], hipStreamNonBlocking, greatest)) != hipSuccess)
-          return cleanup(hip_fail(e, "hipStreamCreate"));
+        if (!plan->is_side[kind]) continue;
         if ((e = hipEventCreateWithFlags(&plan->side_done[kind], hipEventDisableTiming)) != hipSuccess)
           return cleanup(hip_fail(e, "hipEventCreate"));
         if ((e = hipEventCreateWithFlags(&plan->side_go[kind], hipEventDisableTiming)) != hipSuccess)
@@ -794,14 +813,17 @@ btr_status btr_gpu_ctx_create(int device, btr_gpu_ctx** out) {
   btr_gpu_ctx* ctx = new btr_gpu_ctx;
   ctx->device = device;
   ctx->area = area;
-  if ((e = hipEventCreateWithFlags(&ctx->lanes_fork, hipEventDisableTiming)) == hipSuccess)
+  if ((e = hipEventCreateWithFlags(&ctx->lanes_fork, hipEventDisableTiming)) == hipSuccess) {
     for (uint32_t k = 0; k < kColumnLanes && e == hipSuccess; k++) {
       e = hipStreamCreateWithFlags(&ctx->lane[k], hipStreamNonBlocking);
       if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->lane_done[k], hipEventDisableTiming);
     }
+    for (uint32_t k = 0; k < kPipeStreams && e == hipSuccess; k++)
+      e = hipStreamCreateWithFlags(&ctx->pipe[k], hipStreamNonBlocking);
+  }
   if (e != hipSuccess) {
     delete ctx;
-    return hip_fail(e, "hipStreamCreate(column lanes)");
+    return hip_fail(e, "hipStreamCreate(context streams)");
   }
   *out = ctx;
   return BTR_OK;
@@ -1018,10 +1040,6 @@ void btr_gpu_plan_destroy(btr_gpu_plan* plan) {
   if (plan->d_order) (void)hipFree(plan->d_order);
   if (plan->d_scratch) (void)hipFree(plan->d_scratch);
   for (uint32_t kind = 0; kind < KERNEL_KINDS; kind++) {
-    if (plan->side[kind]) {
-      (void)hipStreamSynchronize(plan->side[kind]);
-      (void)hipStreamDestroy(plan->side[kind]);
-    }
     if (plan->side_done[kind]) (void)hipEventDestroy(plan->side_done[kind]);
     if (plan->side_go[kind]) (void)hipEventDestroy(plan->side_go[kind]);
   }
@@ -1065,24 +1083,45 @@ btr_status btr_gpu_decode(btr_gpu_ctx* ctx, btr_gpu_plan* plan, void* hip_stream
                        plan->d_items, plan->d_order + plan->kind_begin[kind], plan->d_programs, plan->d_status);
     return hipGetLastError();
   };
+  if (plan->n_launches <= 1) {
+    if (plan->n_launches) HIP_TRY(launch(plan->main_kind, stream));
+    return BTR_OK;
+  }
+  std::lock_guard<std::recursive_mutex> lock(ctx->streams_mutex);
+  HIP_TRY(hipEventRecord(plan->fork, stream));
+  if (plan->balanced) {
+    // several large launches: the longest on the caller's stream, the others on the context's lanes
+    HIP_TRY(launch(plan->main_kind, stream));
+    for (uint32_t j = 1; j < plan->n_launches; j++) {
+      const uint32_t kind = plan->launch_order[j];
+      hipStream_t on = ctx->lane[(j - 1) % kColumnLanes];
+      if (on == stream) {  // the caller decodes on one of the lanes (btr_gpu_decode_columns)
+        HIP_TRY(launch(kind, stream));
+        continue;
+      }
+      HIP_TRY(hipStreamWaitEvent(on, plan->fork, 0));
+      HIP_TRY(launch(kind, on));
+      HIP_TRY(hipEventRecord(plan->side_done[kind], on));
+      HIP_TRY(hipStreamWaitEvent(stream, plan->side_done[kind], 0));
+    }
+    return BTR_OK;
+  }
   // The small launches fork from the caller's stream first, the main one follows on the stream
   // itself, then the stream waits for the side streams. The main launch waits for an event that each
   // side stream records right before its own launch: the few workgroups of a side launch (which may
   // need more LDS than the main launch leaves free on any CU) are then dispatched onto an empty GPU
   // instead of queueing for a slot until the main grid has been handed out.
-  if (plan->fork) HIP_TRY(hipEventRecord(plan->fork, stream));
-  for (uint32_t kind = 0; kind < KERNEL_KINDS; kind++) {
-    if (!plan->side[kind]) continue;
-    HIP_TRY(hipStreamWaitEvent(plan->side[kind], plan->fork, 0));
-    HIP_TRY(hipEventRecord(plan->side_go[kind], plan->side[kind]));
-    HIP_TRY(launch(kind, plan->side[kind]));
-    HIP_TRY(hipEventRecord(plan->side_done[kind], plan->side[kind]));
+  for (uint32_t j = 1; j < plan->n_launches; j++) {
+    const uint32_t kind = plan->launch_order[j];
+    hipStream_t on = ctx->lane[ctx->next_side++ % kColumnLanes];
+    HIP_TRY(hipStreamWaitEvent(on, plan->fork, 0));
+    HIP_TRY(hipEventRecord(plan->side_go[kind], on));
+    HIP_TRY(launch(kind, on));
+    HIP_TRY(hipEventRecord(plan->side_done[kind], on));
   }
-  for (uint32_t kind = 0; kind < KERNEL_KINDS; kind++)
-    if (plan->side[kind]) HIP_TRY(hipStreamWaitEvent(stream, plan->side_go[kind], 0));
+  for (uint32_t j = 1; j < plan->n_launches; j++) HIP_TRY(hipStreamWaitEvent(stream, plan->side_go[plan->launch_order[j]], 0));
   HIP_TRY(launch(plan->main_kind, stream));
-  for (uint32_t kind = 0; kind < KERNEL_KINDS; kind++)
-    if (plan->side[kind]) HIP_TRY(hipStreamWaitEvent(stream, plan->side_done[kind], 0));
+  for (uint32_t j = 1; j < plan->n_launches; j++) HIP_TRY(hipStreamWaitEvent(stream, plan->side_done[plan->launch_order[j]], 0));
   return BTR_OK;
 }
 
@@ -1097,7 +1136,7 @@ btr_status btr_gpu_decode_columns(btr_gpu_ctx* ctx, btr_gpu_plan* const* plans, 
   DeviceGuard guard(ctx->device);
   if (!guard.ok) return fail(BTR_ERR_DEVICE, "hipSetDevice failed");
   hipStream_t stream = (hipStream_t)hip_stream;
-  std::lock_guard<std::mutex> lock(ctx->lanes_mutex);
+  std::lock_guard<std::recursive_mutex> lock(ctx->streams_mutex);
   const uint32_t used = (uint32_t)std::min<size_t>(n, kColumnLanes);
   HIP_TRY(hipEventRecord(ctx->lanes_fork, stream));
   for (uint32_t k = 0; k < used; k++) HIP_TRY(hipStreamWaitEvent(ctx->lane[k], ctx->lanes_fork, 0));
@@ -1128,7 +1167,7 @@ btr_status btr_gpu_decode_chunks_noalloc(btr_gpu_ctx* ctx, const btr_chunk_desc*
   btr_plan_stats stats{};
   Layout lo;
   try {
-    const btr_status st = compile_chunks(chunks, n, items, progs, stats);
+    const btr_status st = compile_chunks(chunks, n, items, progs, stats, 1);  // on the calling thread: no threads are started
     if (st != BTR_OK) return st;
     lay_out(items, progs, stats, lo);
   } catch (const std::bad_alloc&) {
@@ -1230,11 +1269,38 @@ btr_status btr_gpu_plan_check(btr_gpu_ctx* ctx, btr_gpu_plan* plan, void* hip_st
     if (plan->h_status[i] && first == ~0ull) first = i;
     any |= plan->h_status[i];
   }
+  // ST_PROGRAM is the one bit the kernels do not reset at the start of a decode: it is cleared here,
+  // once it has been read
+  if (any & ST_PROGRAM) HIP_TRY(hipMemset(plan->d_status, 0, plan->n_items * 4));
   if (status_or) *status_or = any;
   if (first_bad) *first_bad = first;
   if (any)
     return fail(BTR_ERR_CORRUPT, "malformed compressed stream in chunk " + std::to_string(first) +
                                      " (status bits 0x" + [&] { char b[16]; snprintf(b, sizeof b, "%x", any); return std::string(b); }() + ")");
+  return BTR_OK;
+}
+
+// ---- test hooks ---------------------------------------------------------------------------------------
+uint32_t btr_debug_launch_entry_check(uint32_t item, uint32_t prog_off, uint32_t prog_bytes) {
+  return launch_entry_check(item, prog_off, prog_bytes);
+}
+
+btr_status btr_gpu_plan_debug_access(btr_gpu_plan* plan, uint32_t region, size_t offset, void* host, size_t bytes,
+                                     int write) {
+  if (!plan || (!host && bytes)) return fail(BTR_ERR_INVALID_ARGUMENT, "null argument");
+  DeviceGuard guard(plan->device);
+  uint8_t* base = nullptr;
+  size_t size = 0;
+  switch (region) {
+    case 0: base = (uint8_t*)plan->d_items, size = plan->n_items * sizeof(WorkItem); break;
+    case 1: base = (uint8_t*)plan->d_order, size = plan->n_items * sizeof(LaunchEntry); break;
+    case 2: base = plan->d_programs, size = plan->program_bytes; break;
+    default: return fail(BTR_ERR_INVALID_ARGUMENT, "unknown region");
+  }
+  if (offset > size || bytes > size - offset) return fail(BTR_ERR_INVALID_ARGUMENT, "range outside the region");
+  HIP_TRY(hipDeviceSynchronize());
+  if (bytes) HIP_TRY(write ? hipMemcpy(base + offset, host, bytes, hipMemcpyHostToDevice)
+                           : hipMemcpy(host, base + offset, bytes, hipMemcpyDeviceToHost));
   return BTR_OK;
 }
 

@@ -1447,11 +1447,17 @@ __device__ __forceinline__ void ring_pass(const Ctx& c, const Pipe& p, const BpV
         // is one) has taken its words out of it
         const u32 published = uniform(lds32(slot_off + 4 * (t & 1)));
         if (t + ahead < batches && published != prev_published) {
-          // bounded: a release that never comes (it cannot) must not hang the GPU
+          // bounded: a release that never comes must not hang the GPU; the batch is then issued over
+          // words that may still be read, so the chunk is reported as not decoded
+          bool released = false;
           for (u32 spin = 0; spin < (1u << 20); spin++) {
-            if (uniform(*reinterpret_cast<volatile const u32*>(lds_raw + ring_release_word(c))) == t + 1) break;
+            if (uniform(*reinterpret_cast<volatile const u32*>(lds_raw + ring_release_word(c))) == t + 1) {
+              released = true;
+              break;
+            }
             __builtin_amdgcn_s_sleep(2);
           }
+          if (!released && lane == 0) raise(c, ST_INTERNAL);
         }
         prev_published = published;
       }
@@ -3122,9 +3128,25 @@ __device__ __forceinline__ void stream_trailing_nullmap(const Ctx& c, const Prog
   }
 }
 
+// A launch entry is checked before the item index or the program place it names is used: an entry
+// that is not one the host wrote (read at a wrong stride, from a stale or foreign buffer) would
+// otherwise send the workgroup through arbitrary memory and loop bounds. Reported on the plan's
+// first status word, the only one that can be named without trusting the entry.
+__device__ __forceinline__ bool entry_ok(const LaunchEntry& e, u32* __restrict__ status) {
+  const u32 item = uniform(e.item), off = uniform(e.prog_off), bytes = uniform(e.prog_bytes);
+  const bool ok = uniform(e.check) == launch_entry_check(item, off, bytes) && bytes >= sizeof(ProgramHeader) &&
+                  bytes <= kMaxProgramBytes && (bytes & 3) == 0 && (off & 3) == 0;
+  if (!ok && threadIdx.x == 0) atomicOr(status, (u32)ST_PROGRAM);
+  return ok;
+}
+
+// Copies the program into LDS at BASE and checks it against the launch entry and the work item
+// before anything is interpreted: `ok` false means the workgroup must return at once (every loop
+// bound, table offset and barrier count below comes out of the program).
 template <u32 THREADS, u32 BASE>
 __device__ __forceinline__ ProgramHeader load_program(const WorkItem& it, const LaunchEntry& entry,
-                                                      const u8* __restrict__ programs, u32* __restrict__ status, Ctx& c) {
+                                                      const u8* __restrict__ programs, u32* __restrict__ status, Ctx& c,
+                                                      bool& ok) {
   const u32 item = entry.item;
   const u32 tid = threadIdx.x;
   c.side = uniform(it.flags) & ITEM_SIDE_LAUNCH;
@@ -3133,14 +3155,30 @@ __device__ __forceinline__ ProgramHeader load_program(const WorkItem& it, const 
     // placed by the launch entry, not by the work item: the copy does not wait for the item's load
     const u32* prog = reinterpret_cast<const u32*>(programs + entry.prog_off);
     for (u32 o = tid; o < entry.prog_bytes / 4; o += THREADS) lds_st32(BASE + 4 * o, prog[o]);
-    if (tid == 0) status[item] = 0;  // later raise() calls are ordered behind the barrier
+    // The item's status word starts clean (later raise() calls are ordered behind the barrier). ST_PROGRAM
+    // is left standing: on the plan's first word it may come from another workgroup of this launch whose
+    // entry was bad; the host clears it when it reads the words.
+    if (tid == 0) atomicAnd(status + item, (u32)ST_PROGRAM);
   }
   __syncthreads();
   ProgramHeader hdr = *reinterpret_cast<const ProgramHeader*>(lds_raw + BASE);
   hdr.n_steps = uniform(hdr.n_steps);
   hdr.n_bp_steps = uniform(hdr.n_bp_steps);
   hdr.n_pipes = uniform(hdr.n_pipes);
+  hdr.n_seqs = uniform(hdr.n_seqs);
   hdr.table_base = uniform(hdr.table_base);
+  hdr.consts_off = uniform(hdr.consts_off);
+  {
+    const u32 bytes = uniform(entry.prog_bytes);
+    constexpr u32 kMany = 4096;  // tables of a program: far fewer in practice, and small enough for 32-bit products
+    const u32 fixed = (u32)sizeof(ProgramHeader) + hdr.n_steps * (u32)sizeof(Step) + hdr.n_pipes * (u32)sizeof(Pipe) +
+                      hdr.n_seqs * (u32)sizeof(Seq);
+    ok = uniform(hdr.magic) == kProgramMagic && uniform(hdr.prog_bytes) == bytes && uniform(it.prog_bytes) == bytes &&
+         uniform(it.prog_off) == uniform(entry.prog_off) && hdr.n_steps >= 1 && hdr.n_steps <= kMany &&
+         hdr.n_bp_steps <= hdr.n_steps && hdr.n_pipes <= kMany && hdr.n_seqs <= kMany && hdr.consts_off == fixed &&
+         fixed <= bytes && hdr.table_base >= BASE + ((bytes + 15) & ~15u) + 64 && hdr.table_base <= kLdsCapBytes;
+    if (!ok && tid == 0) atomicOr(status + item, (u32)ST_PROGRAM);
+  }
   c.src = reinterpret_cast<const u8*>(it.src);
   c.dst = reinterpret_cast<u8*>(it.dst);
   c.nullmap = reinterpret_cast<u8*>(it.nullmap_dst);
@@ -3151,7 +3189,7 @@ __device__ __forceinline__ ProgramHeader load_program(const WorkItem& it, const 
   c.seqs_off = c.pipes_off + hdr.n_pipes * sizeof(Pipe);
   c.table_base = hdr.table_base;
   c.red_off = hdr.table_base - 64;
-  c.consts_off = BASE + uniform(hdr.consts_off);
+  c.consts_off = BASE + hdr.consts_off;
   c.debug = it.debug_flags;
   c.debug_buf = it.debug_buf;
   return hdr;
@@ -3184,10 +3222,13 @@ template <u32 PS, bool NM>
 __device__ __forceinline__ void stream_block(const WorkItem* __restrict__ items, const LaunchEntry* __restrict__ order,
                                              const u8* __restrict__ programs, u32* __restrict__ status) {
   const LaunchEntry entry = order[blockIdx.x];
+  if (!entry_ok(entry, status)) return;
   const u32 item = entry.item;
   const WorkItem it = items[item];
   Ctx c;
-  const ProgramHeader hdr = load_program<kStreamThreads, kStreamProgBase>(it, entry, programs, status, c);
+  bool ok;
+  const ProgramHeader hdr = load_program<kStreamThreads, kStreamProgBase>(it, entry, programs, status, c, ok);
+  if (!ok) return;
   const u32 root_idx = NM ? stream_root_index(c, hdr) : hdr.n_steps - 1;
   const Step& root = step_at(c, root_idx);
   const u32 pipe_id = uniform(root.a[0]);
@@ -3211,11 +3252,14 @@ template <bool NM>
 __device__ __forceinline__ void stream_dictd_block(const WorkItem* __restrict__ items, const LaunchEntry* __restrict__ order,
                                                    const u8* __restrict__ programs, u32* __restrict__ status) {
   const LaunchEntry entry = order[blockIdx.x];
+  if (!entry_ok(entry, status)) return;
   const u32 item = entry.item;
   const WorkItem it = items[item];
   Ctx c;
   stamp(it, 0);
-  const ProgramHeader hdr = load_program<kDictdThreads, kStreamProgBase>(it, entry, programs, status, c);
+  bool ok;
+  const ProgramHeader hdr = load_program<kDictdThreads, kStreamProgBase>(it, entry, programs, status, c, ok);
+  if (!ok) return;
   const u32 root_idx = NM ? stream_root_index(c, hdr) : hdr.n_steps - 1;
   const Step& root = step_at(c, root_idx);
   if (uniform(threadIdx.x >> 6) == kDictdWaves - 1) {  // first payload batches beside the dictionary copy
@@ -3241,11 +3285,14 @@ template <bool NM>
 __device__ __forceinline__ void stream_pseudo_block(const WorkItem* __restrict__ items, const LaunchEntry* __restrict__ order,
                                                     const u8* __restrict__ programs, u32* __restrict__ status) {
   const LaunchEntry entry = order[blockIdx.x];
+  if (!entry_ok(entry, status)) return;
   const u32 item = entry.item;
   const WorkItem it = items[item];
   Ctx c;
   stamp(it, 0);
-  const ProgramHeader hdr = load_program<kStreamThreads, kStreamProgBase>(it, entry, programs, status, c);
+  bool ok;
+  const ProgramHeader hdr = load_program<kStreamThreads, kStreamProgBase>(it, entry, programs, status, c, ok);
+  if (!ok) return;
   stamp(it, 1);
   const u32 root_idx = NM ? stream_root_index(c, hdr) : hdr.n_steps - 1;
   const Step& root = step_at(c, root_idx);
@@ -3314,6 +3361,7 @@ template <bool DOUBLE_KERNEL, bool WITH_PFOR>
 __device__ __forceinline__ void decode_block(const WorkItem* __restrict__ items, const LaunchEntry* __restrict__ order,
                                     const u8* __restrict__ programs, u32* __restrict__ status) {
   const LaunchEntry entry = order[blockIdx.x];
+  if (!entry_ok(entry, status)) return;
   const u32 item = entry.item;
   const WorkItem it = items[item];
   const u32 tid = threadIdx.x;
@@ -3335,7 +3383,9 @@ __device__ __forceinline__ void decode_block(const WorkItem* __restrict__ items,
       }
     }
   }
-  const ProgramHeader hdr = load_program<kBlockThreads, 0>(it, entry, programs, status, c);
+  bool ok;
+  const ProgramHeader hdr = load_program<kBlockThreads, 0>(it, entry, programs, status, c, ok);
+  if (!ok) return;
   stamp(it, 1);
 
   // bit-unpack indexes: one stream per wave, streams in parallel

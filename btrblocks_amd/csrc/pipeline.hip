@@ -3,7 +3,8 @@
 // feeds them to BtrReader objects. Included by c_api.hip (it uses that file's plan compiler and
 // kernel table).
 //
-// A pipeline owns `slots` sets of device buffers and three streams. For part p, in slot p % slots:
+// A pipeline owns `slots` sets of device buffers and borrows the context's three pipeline streams
+// (pipelines of one context share them). For part p, in slot p % slots:
 //   host      header walk + program compilation of the part (the work BtrReader::readColumn does
 //             per chunk, BtrReader.cpp:31-74), into the slot's pinned staging area
 //   copy-in   part image and programs host -> device
@@ -127,8 +128,7 @@ btr_status btr_gpu_pipeline_create(btr_gpu_ctx* ctx, uint32_t slots, btr_gpu_pip
     return st;
   };
   hipError_t e;
-  for (hipStream_t* s : {&p->s_in, &p->s_dec, &p->s_out})
-    if ((e = hipStreamCreateWithFlags(s, hipStreamNonBlocking)) != hipSuccess) return cleanup(hip_fail(e, "hipStreamCreate"));
+  p->s_in = ctx->pipe[0], p->s_dec = ctx->pipe[1], p->s_out = ctx->pipe[2];  // owned by the context
   for (PipeSlot& s : p->slots)
     for (hipEvent_t* ev : {&s.in_done, &s.decode_done, &s.out_done})
       if ((e = hipEventCreateWithFlags(ev, hipEventDisableTiming)) != hipSuccess) return cleanup(hip_fail(e, "hipEventCreate"));
@@ -152,8 +152,6 @@ void btr_gpu_pipeline_destroy(btr_gpu_pipeline* p) {
     for (hipEvent_t ev : {s.in_done, s.decode_done, s.out_done})
       if (ev) (void)hipEventDestroy(ev);
   }
-  for (hipStream_t s : {p->s_in, p->s_dec, p->s_out})
-    if (s) (void)hipStreamDestroy(s);
   delete p;
 }
 

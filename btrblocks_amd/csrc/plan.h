@@ -116,9 +116,15 @@ struct ProgramHeader {
   uint32_t table_base;  // absolute LDS byte offset where table space starts (after the program copy
                         // and 64 bytes of reduction scratch)
   uint32_t consts_off;  // byte offset of the constant words from the start of the program
-  uint32_t pad[2];
+  uint32_t magic;       // kProgramMagic
+  uint32_t prog_bytes;  // size of the whole program: must equal what the launch entry and the work item say
 };
 // A program is laid out as: ProgramHeader | Step[n_steps] | Pipe[n_pipes] | Seq[n_seqs] | u32 consts[]
+// A workgroup checks the header it has copied before it interprets anything (loop bounds, table
+// offsets and barrier counts all come out of the program): a launch entry or program that is not
+// the one the host wrote ends the workgroup with ST_PROGRAM instead of a long or endless loop.
+constexpr uint32_t kProgramMagic = 0x50525442u;      // "BTRP"
+constexpr uint32_t kMaxProgramBytes = 64u * 1024u;   // programs are a few hundred bytes to a few KiB
 
 struct WorkItem {
   uint64_t src;          // device address of the chunk envelope / block column payload base
@@ -146,9 +152,14 @@ struct LaunchEntry {
   uint32_t item;
   uint32_t prog_off;
   uint32_t prog_bytes;
-  uint32_t pad;
+  uint32_t check;  // launch_entry_check(item, prog_off, prog_bytes)
 };
 static_assert(sizeof(LaunchEntry) == 16, "one 16-byte scalar load");
+// Mixes the three fields of a launch entry: an entry read from the wrong place (a stale or
+// mis-strided launch order) fails the comparison before its item index or program place is used.
+constexpr uint32_t launch_entry_check(uint32_t item, uint32_t prog_off, uint32_t prog_bytes) {
+  return (item * 0x9E3779B1u) ^ (prog_off * 0x85EBCA6Bu) ^ (prog_bytes * 0xC2B2AE35u) ^ kProgramMagic;
+}
 // The item belongs to a small launch that runs on a side stream beside the plan's main launch: its
 // waves raise their priority, or they would crawl among the main launch's waves and end long after it.
 enum : uint32_t { ITEM_SIDE_LAUNCH = 1u << 0 };
@@ -162,6 +173,9 @@ enum : uint32_t {
   ST_PSEUDO = 1u << 4,      // exception count differs from tuple_count - converted_count
   ST_ROARING = 1u << 5,     // member outside the row range or cardinality mismatch
   ST_EXPONENT = 1u << 6,    // Pseudodecimal exponent index above 22
+  ST_PROGRAM = 1u << 7,     // launch entry, work item or decode program inconsistent (raised on the item's word;
+                            // on word 0 of the plan when the launch entry itself cannot be trusted)
+  ST_INTERNAL = 1u << 8,    // a bounded wait inside a kernel ran out: the output of that chunk is not valid
 };
 
 // Which kernel decodes a work item. The generic kernels interpret any program; the stream kernels

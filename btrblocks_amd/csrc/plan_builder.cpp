@@ -941,6 +941,10 @@ void build_program(const ColumnSource& src, BuiltProgram& out) {
   hdr.n_seqs = (uint32_t)bld.seqs.size();
   hdr.table_base = table_base;
   hdr.consts_off = (uint32_t)consts_off;
+  hdr.magic = kProgramMagic;
+  hdr.prog_bytes = (uint32_t)prog_bytes_final;
+  if (prog_bytes_final > kMaxProgramBytes)
+    throw PlanError(ST_UNSUPPORTED, "decode program of this chunk above " + std::to_string(kMaxProgramBytes) + " bytes");
   memcpy(p, &hdr, sizeof(hdr));
   p += sizeof(hdr);
   if (!bld.bp_steps.empty()) memcpy(p, bld.bp_steps.data(), bld.bp_steps.size() * sizeof(Step));

@@ -245,8 +245,10 @@ btr_status btr_gpu_decode(btr_gpu_ctx* ctx, btr_gpu_plan* plan, void* hip_stream
  * destinations must not overlap. Two launches of the same plan must not overlap either. */
 btr_status btr_gpu_decode_columns(btr_gpu_ctx* ctx, btr_gpu_plan* const* plans, size_t n, void* hip_stream);
 
-/* btr_gpu_plan_create + btr_gpu_decode (+ btr_gpu_plan_check) in one call that allocates nothing:
- * no hipMalloc / hipFree, no stream or event creation. It has no counterpart in the reference; it
+/* btr_gpu_plan_create + btr_gpu_decode (+ btr_gpu_plan_check) in one call that allocates nothing
+ * on the device or in the HIP runtime: no hipMalloc / hipFree / hipHostMalloc, no stream or event
+ * creation. (On the host it compiles the chunks' programs into ordinary heap memory, on the
+ * calling thread only.) It has no counterpart in the reference; it
  * exists for callers that cannot allocate - tight serving loops and harnesses that forbid
  * hipMalloc on the decode path. Inputs and outputs are the caller's device buffers, as in
  * btr_gpu_plan_create. Everything a plan would allocate on the device (work items, programs,
@@ -265,6 +267,16 @@ btr_status btr_gpu_decode_chunks_noalloc(btr_gpu_ctx* ctx, const btr_chunk_desc*
  * Generic_Exception("Decompressing XPBP failed") (integer/PBP.cpp:44-47). */
 btr_status btr_gpu_plan_check(btr_gpu_ctx* ctx, btr_gpu_plan* plan, void* hip_stream,
                               uint32_t* status_or, uint64_t* first_bad);
+
+/* Test hooks (no counterpart in the reference). btr_gpu_plan_debug_access reads (write == 0) or
+ * overwrites `bytes` bytes at `offset` of one of a plan's device tables - region 0: work items,
+ * 1: launch entries, 2: program blob - after a device synchronisation; the tests use it to hand a
+ * workgroup a launch entry or program that is not the one the host compiled and to check that the
+ * decode ends with BTR_ERR_CORRUPT (status bit 0x80) instead of interpreting it.
+ * btr_debug_launch_entry_check is the check word of a launch entry {item, prog_off, prog_bytes}. */
+btr_status btr_gpu_plan_debug_access(btr_gpu_plan* plan, uint32_t region, size_t offset, void* host, size_t bytes,
+                                     int write);
+uint32_t btr_debug_launch_entry_check(uint32_t item, uint32_t prog_off, uint32_t prog_bytes);
 
 /* Host-in / host-out decode of one chunk: BtrReader::readColumn (BtrReader.cpp:31-74) with the
  * nullmap of BitmapWrapper::writeBITMAP (extern/RoaringBitmap.cpp:32-53). Copies the chunk to the

@@ -2,8 +2,8 @@
 # usage (from the repository root): tools/gpu_variants_rel.sh "<variant names>" <rows> [bench flags]
 # The mixed relation (bench.py --relation) with experiment builds against the product library.
 mkdir -p gpurun_out
-rows=$2; shift 2 || true
-for v in product $VARIANTS; do
+variants=$1; rows=$2; shift 2 || true
+for v in product $variants; do
   if [ $v = product ]; then unset BTR_LIB_PATH; else export BTR_LIB_PATH=$PWD/btrblocks_amd/libbtrblocks_amd_$v.so; fi
   timeout -k 10 300 python -u bench.py --relation --rows $rows --steps 20 --warmup 3 --no-cpu-baseline --no-pipeline --no-verify "$@" > gpurun_out/rel_$v.log 2>&1 || { tail -5 gpurun_out/rel_$v.log; exit 1; }
   python - <<PY
