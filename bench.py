@@ -11,7 +11,8 @@ columns with the compressed chunks already resident in HBM.
 N > 1: ONE mixed relation of 8 int32 + 4 double columns x `--rows` rows (16 GiB raw; nested
 cascades of depth 3) whose blocks are sharded over the ranks as contiguous block ranges balanced
 by decoded bytes (btrblocks_amd.shard.shard_ranges); every rank generates, compresses, uploads and
-decodes only its own range; no data-path collective. The relation does not depend on N (it is
+decodes only its own range, through ONE decode plan over the chunks of all its columns; no
+data-path collective. The relation does not depend on N (it is
 generated in segments of 512 blocks with fixed seeds), so scaling is strong and `value` is the
 whole relation's decoded bytes over the slowest rank's time.
 Launch: `python bench.py --gpus N` spawns the N ranks itself (one process per GPU) when it was
@@ -21,7 +22,7 @@ WORLD_SIZE from the environment.
 Prints ONE JSON line: metric/value (GB/s of uncompressed output, whole job), `roofline`
 (algorithmic bytes = compressed bytes the decoder needs + decoded bytes written, per launch,
 over the HIP-event duration of the decode kernel) and `cpu_baseline` (the CPU oracle's restated
-decompression-speed harness on a bounded sample of the same chunks, rank 0 at N=1 only).
+decompression-speed harness on a bounded sample of rank 0's chunks, on rank 0's host cores).
 """
 import argparse
 import json
@@ -262,6 +263,9 @@ def parse_args():
                     help="N = 1: after the timed region, time the same step with the columns beside each other as well "
                          "(columns_beside_each_other; its launches overlap, so leave it out of profiled runs)")
     ap.add_argument("--serial", action="store_true", help="N > 1: one column launch after the other, as at N = 1")
+    ap.add_argument("--per-column-plans", action="store_true",
+                    help="mixed relation: one plan per column, decoded beside each other, instead of ONE plan over the "
+                         "chunks of all columns of the rank's block range (launches = kernel kinds, longest first)")
     ap.add_argument("--no-verify", action="store_true", help="skip the oracle check of a sample of blocks after the timed region")
     ap.add_argument("--verify-stride", type=int, default=257, help="check every N-th chunk (and the last one)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
@@ -363,9 +367,22 @@ def run_rank(args):
             dist.barrier()
         torch.cuda.synchronize()
 
-    concurrent = (args.concurrent or world > 1) and not args.serial and len(plans) > 1
+    # The mixed relation is handed over whole: one plan over the chunks of ALL columns of this rank's
+    # block range, as decompression-speed.cpp:45-58 gives every column x part x chunk to one scheduler.
+    # Its launches are kernel kinds (longest first), not columns.
+    rel_plan = None
+    if relation and not args.serial and not args.concurrent and not args.per_column_plans and len(readers) > 1:
+        t0 = time.time()
+        descs = [r._desc(i, want_nm) for r in readers for i in range(len(r.chunks))]
+        rel_plan = api.DecodePlan(ctx, descs, keepalive=tuple(readers))
+        t_rel_plan = time.time() - t0
+        rel_stats = rel_plan.stats
+    concurrent = rel_plan is not None or ((args.concurrent or world > 1) and not args.serial and len(plans) > 1)
 
     def step(events=None):
+        if rel_plan is not None:
+            rel_plan.decode(stream)
+            return
         if concurrent:  # the columns beside each other; per-launch events would time overlapped launches
             api.decode_columns(ctx, plans, stream)
             return
@@ -379,7 +396,7 @@ def run_rank(args):
     for _ in range(args.warmup):
         step()
     barrier()
-    for p in plans:  # malformed-stream flags of the warm-up passes
+    for p in plans + ([rel_plan] if rel_plan is not None else []):  # malformed-stream flags of the warm-up passes
         p.check(stream)
 
     evs = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in plans]
@@ -391,7 +408,7 @@ def run_rank(args):
     barrier()
     t1 = time.perf_counter()
     elapsed = t1 - t0
-    for p in plans:
+    for p in plans + ([rel_plan] if rel_plan is not None else []):
         p.check(stream)
     verified = 0
     if not args.no_verify:
@@ -471,14 +488,28 @@ def run_rank(args):
     achieved_all = alg_bytes / (mean_ms.sum() / 1e3) / 1e9   # GB/s over all launches of a step
 
     if rank == 0:
-        traffic = None
+        # HBM bytes per launch of the dominant kernel: not collected in this run (counters need rocprofv3
+        # passes of their own, profiles/collect.sh) but read from the tracked summary of those passes. The
+        # passes ran the N = 1 default columns; for any other launch size the kernel's measured ratio of
+        # traffic to algorithmic bytes is applied to this launch's algorithmic bytes, and the source says so.
+        traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath) and world == 1 and args.rows == 268435456:
-            try:  # HBM bytes per launch from the PMC passes of the same columns (profiles/collect.sh)
-                traffic = json.load(open(tpath)).get("bytes_per_launch", {}).get(
-                    per_column[cols[dom]["name"]]["kernels"][0])
+        if os.path.exists(tpath):
+            try:
+                summary = json.load(open(tpath))
+                kern = per_column[cols[dom]["name"]]["kernels"][0]
+                tag = summary.get("tag", "untagged")
+                detail = summary.get("detail", {}).get(kern)
+                if detail is not None and detail.get("algorithmic_bytes") == dom_alg:
+                    traffic = summary["bytes_per_launch"][kern]
+                    traffic_source = f"profiles/pmc_traffic.json ({tag}): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload"
+                elif detail is not None:
+                    traffic = int(round(detail["traffic_over_algorithmic"] * dom_alg))
+                    traffic_source = (f"profiles/pmc_traffic.json ({tag}): {kern} moved {detail['traffic_over_algorithmic']} x its "
+                                      f"algorithmic bytes in the counter passes of column '{detail['column']}' at 4096 blocks; "
+                                      "that ratio times this launch's algorithmic bytes")
             except Exception:
-                traffic = None
+                traffic, traffic_source = None, None
         dtypes = sorted({"f64" if column_elem_bytes(n) == 8 else "int32" for n in names})
         line = {
             "metric": "device-resident decompression GB/s (uncompressed output)",
@@ -504,7 +535,10 @@ def run_rank(args):
                 "total_output_bytes": int(total_out),
                 "rank0_output_bytes": int(out_bytes),
                 "sharding": "independent block ranges per GPU, no collective",
-                "launches": ("columns beside each other (btr_gpu_decode_columns); roofline.per_column timed one launch after "
+                "launches": ("ONE plan over the chunks of all columns of the rank's block range (launches = kernel kinds, longest "
+                             "first, beside each other); roofline.per_column timed one column launch after the other outside "
+                             "the timed region" if rel_plan is not None else
+                             "columns beside each other (btr_gpu_decode_columns); roofline.per_column timed one launch after "
                              "the other outside the timed region" if concurrent else "one column launch after the other"),
                 "verified_chunks": verified_all,
             },
@@ -515,6 +549,7 @@ def run_rank(args):
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": traffic,
+                "traffic_source": traffic_source,
                 "kernel": ",".join(per_column[cols[dom]["name"]]["kernels"]),
                 "column": cols[dom]["name"],
                 "alg_bytes_per_launch": int(dom_alg),
@@ -542,8 +577,12 @@ def run_rank(args):
                                                  "what": "the same step through btr_gpu_decode_columns; not the value of this line"}
         if world == 1 and not args.no_pipeline:
             line["host"]["pipeline"] = pipeline_rate(ctx, cols)
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(cols, args.cpu_sample_chunks)
+        if rel_plan is not None:
+            line["relation_plan"] = {"chunks": int(rel_stats.chunks), "launches_per_step": int(rel_stats.launches),
+                                     "kernels": kernel_names(rel_stats.kernel_mask), "plan_s": round(t_rel_plan, 3),
+                                     "compile_s": round(rel_stats.compile_seconds, 4)}
+        if not args.no_cpu_baseline:  # rank 0's host cores, on rank 0's own chunks
+            line["cpu_baseline"] = cpu_baseline(cols, min(args.cpu_sample_chunks, max(8, 3072 // len(cols))))
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

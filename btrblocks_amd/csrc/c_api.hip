@@ -146,6 +146,20 @@ StaticArea g_static_area[kMaxDevices];
 std::mutex g_static_mutex;
 }  // namespace
 
+namespace {
+// Kernel of a launch: a kernel kind, or one of the two mixed stream kernels.
+constexpr uint32_t kMixedStream = KERNEL_KINDS, kMixedStreamNm = KERNEL_KINDS + 1;
+// One kernel launch: the entries [begin, begin + count) of the launch order.
+struct LaunchGroup {
+  uint32_t kernel = 0;   // kernel kind, kMixedStream or kMixedStreamNm
+  uint32_t threads = 0;  // workgroup size
+  uint32_t lds = 0;      // dynamic LDS bytes: the largest need among its chunks
+  size_t begin = 0, count = 0;
+  uint64_t weight = 0;   // decoded bytes, scaled by how long a byte of this kind takes (launch_cost)
+  LaunchSegments seg{};  // mixed kernels: which workgroups run which kind
+};
+}  // namespace
+
 // Every stream the library uses besides the caller's lives in the context, created with it and
 // destroyed with it. Plans and pipelines borrow them: nothing on the decode path creates or destroys
 // a stream. All of them are plain non-blocking streams, which HIP multiplexes onto the process's
@@ -153,7 +167,7 @@ std::mutex g_static_mutex;
 // gets a hardware queue of its own beyond those four, and a launch on the caller's stream that
 // waits for an event of that queue was seen to never start once the other queues were in use (a
 // plan of several kernel kinds decoded right behind other plans; the device then never went idle).
-constexpr uint32_t kColumnLanes = 3;   // with the caller's stream: four launches beside each other
+constexpr uint32_t kColumnLanes = 4;   // with the caller's stream: four launches beside each other
 constexpr uint32_t kPipeStreams = 3;   // copy-in, decode and copy-out streams of the part pipelines
 
 struct btr_gpu_ctx {
@@ -190,21 +204,17 @@ struct btr_gpu_plan {
   uint8_t* d_programs = nullptr;
   size_t program_bytes = 0;
   uint32_t* d_status = nullptr;
-  LaunchEntry* d_order = nullptr;  // launch entries (work item index, program place) grouped by the kernel that decodes them
-  size_t kind_begin[KERNEL_KINDS + 1] = {};
-  uint32_t kind_lds[KERNEL_KINDS] = {};  // dynamic LDS per launch
+  LaunchEntry* d_order = nullptr;  // launch entries (work item index, program place), launch by launch
   uint8_t* d_scratch = nullptr;
   uint32_t* d_debug = nullptr;  // BTR_DEBUG_FLAGS & 8: kDebugSlots timestamps per work item
-  // A plan with several kernel kinds launches all but the first of `launch_order` on lanes of the
-  // context, which fork from and join the caller's stream by the plan's events: a handful of odd
-  // chunks then decode beside the main launch instead of adding their whole latency behind it.
-  bool is_side[KERNEL_KINDS] = {};
-  hipEvent_t side_done[KERNEL_KINDS] = {};
-  hipEvent_t side_go[KERNEL_KINDS] = {};  // recorded on a side stream right before its launch: the main launch waits for it
+  // The launches of a decode, the one with the most decoded bytes first. A plan with several of
+  // them runs them beside each other on lanes of the context, which fork from and join the
+  // caller's stream by the plan's events.
+  std::vector<LaunchGroup> launches;
+  std::vector<uint32_t> lane;       // per launch: 0 = the caller's stream, k = lane k - 1 of the context
+  std::vector<hipEvent_t> done;     // per launch that runs on a lane: recorded behind it
+  std::vector<hipEvent_t> go;       // small side launches: recorded right before the launch; the main launch waits for it
   hipEvent_t fork = nullptr;
-  uint32_t main_kind = 0;
-  uint32_t launch_order[KERNEL_KINDS] = {};  // kinds with chunks, the one with the most decoded bytes first
-  uint32_t n_launches = 0;
   bool balanced = false;  // several large launches (a relation-level plan): no small odd launches to favour
   btr_plan_stats stats{};
   std::vector<uint32_t> h_status;
@@ -317,14 +327,51 @@ uint32_t debug_flags_from_env() {
   return flags;
 }
 
-// Program blob, launch order and per-kind launch geometry of a set of compiled chunks.
+// Program blob, launch order and launches of a set of compiled chunks.
 struct Layout {
   std::vector<uint8_t> blob;
   std::vector<LaunchEntry> order;
-  size_t kind_begin[KERNEL_KINDS + 1] = {};
-  uint32_t kind_lds[KERNEL_KINDS] = {};
+  std::vector<LaunchGroup> launches;  // the one with the most decoded bytes first
   uint64_t scratch = 0;
 };
+
+unsigned threads_of(uint32_t kind) {
+  return kind == KERNEL_STREAM_DICTD || kind == KERNEL_STREAM_DICTD + KERNEL_STREAM_NULLMAP ? kDictdThreads
+         : kernel_is_generic(kind)                                                         ? kBlockThreads
+                                                                                           : kStreamThreads;
+}
+bool kind_is_double(uint32_t kind) {
+  const uint32_t k = kind >= KERNEL_STREAM_NONE + KERNEL_STREAM_NULLMAP ? kind - KERNEL_STREAM_NULLMAP : kind;
+  return k == KERNEL_GENERIC_DBL || k == KERNEL_STREAM_PSEUDO || k == KERNEL_STREAM_DICTD || k == KERNEL_PFOR_DBL;
+}
+// Workgroups of a kernel kind that share a CU when each needs `lds` bytes of LDS. The dynamic LDS
+// size belongs to the launch, so chunks that need little would be held to the occupancy of the
+// neediest chunk of their launch: chunks are grouped into launches by this figure.
+uint32_t workgroups_per_cu(uint32_t kind, uint32_t lds) {
+  const uint32_t by_waves = kind == KERNEL_GENERIC_INT ? 6 : kernel_is_generic(kind) ? 4 : threads_of(kind) == kDictdThreads ? 2 : 4;
+  const uint32_t by_lds = kLdsCapBytes / std::max<uint32_t>(512, (lds + 511) / 512 * 512);
+  return std::max<uint32_t>(1, std::min(by_waves, by_lds));
+}
+// Rough relative time to decode one byte with a kernel kind (measured on whole columns; only the
+// ratios matter): used to deal launches to lanes so that the lanes finish together.
+uint32_t launch_cost(uint32_t kind, uint32_t per_cu) {
+  switch (kind >= KERNEL_STREAM_NONE + KERNEL_STREAM_NULLMAP ? kind - KERNEL_STREAM_NULLMAP : kind) {
+    case KERNEL_GENERIC_INT: return 22;
+    case KERNEL_GENERIC_DBL: return per_cu <= 3 ? 40 : 22;  // programs with many tables: nested Pseudodecimal
+    case KERNEL_STREAM_PSEUDO: return 34;
+    case KERNEL_STREAM_DICTD: return 25;
+    case KERNEL_PFOR_INT:
+    case KERNEL_PFOR_DBL: return 33;
+    default: return 29;
+  }
+}
+// The 512-thread stream kinds can share a launch (the mixed kernels); 0 = the kind launches alone.
+uint32_t mixed_kernel_of(uint32_t kind) {
+  if (kind >= KERNEL_STREAM_NONE && kind <= KERNEL_STREAM_PSEUDO) return kMixedStream;
+  if (kind >= KERNEL_STREAM_NONE + KERNEL_STREAM_NULLMAP && kind <= KERNEL_STREAM_PSEUDO + KERNEL_STREAM_NULLMAP) return kMixedStreamNm;
+  return 0;
+}
+
 void lay_out(std::vector<WorkItem>& items, const std::vector<BuiltProgram>& progs, btr_plan_stats& stats, Layout& lo) {
   size_t total = 0;
   for (const BuiltProgram& p : progs) total += (p.program.size() + 15) / 16 * 16;
@@ -341,30 +388,77 @@ void lay_out(std::vector<WorkItem>& items, const std::vector<BuiltProgram>& prog
     stats.max_lds_bytes = std::max(stats.max_lds_bytes, progs[i].lds_bytes);
     stats.max_depth = std::max(stats.max_depth, progs[i].depth);
     stats.needed_bytes += progs[i].needed_bytes;
+    stats.kernel_mask |= 1u << progs[i].kernel;
   }
   stats.scratch_bytes = lo.scratch;
   stats.chunks = items.size();
-  lo.order.reserve(items.size());
-  for (uint32_t kind = 0; kind < KERNEL_KINDS; kind++) {
-    lo.kind_begin[kind] = lo.order.size();
-    for (size_t i = 0; i < items.size(); i++)
-      if (progs[i].kernel == kind) {
-        lo.order.push_back(LaunchEntry{(uint32_t)i, items[i].prog_off, items[i].prog_bytes,
-                                       launch_entry_check((uint32_t)i, items[i].prog_off, items[i].prog_bytes)});
-        lo.kind_lds[kind] = std::max(lo.kind_lds[kind], progs[i].lds_bytes);
-      }
-  }
-  lo.kind_begin[KERNEL_KINDS] = lo.order.size();
-  for (uint32_t kind = 0; kind < KERNEL_KINDS; kind++)
-    if (lo.kind_begin[kind + 1] > lo.kind_begin[kind]) {
-      stats.kernel_mask |= 1u << kind;
-      stats.launches++;
+  // A launch holds the chunks of one kernel (a kernel kind, or the stream kinds a mixed kernel
+  // covers) that run the same number of workgroups per CU. Inside a launch the kinds whose blocks
+  // take longest come first (the workgroups handed out last are then the short ones), chunks of a
+  // kind in the order they were given.
+  struct Key {
+    uint32_t kernel, per_cu;
+    bool operator==(const Key& o) const { return kernel == o.kernel && per_cu == o.per_cu; }
+  };
+  std::vector<Key> keys;
+  std::vector<std::vector<uint32_t>> members;
+  for (size_t i = 0; i < items.size(); i++) {
+    const uint32_t kind = progs[i].kernel, mixed = mixed_kernel_of(kind);
+    const Key key{mixed ? mixed : kind, workgroups_per_cu(kind, progs[i].lds_bytes)};
+    size_t g = 0;
+    while (g < keys.size() && !(keys[g] == key)) g++;
+    if (g == keys.size()) {
+      keys.push_back(key);
+      members.emplace_back();
     }
-}
-
-bool kind_is_double(uint32_t kind) {
-  const uint32_t k = kind >= KERNEL_STREAM_NONE + KERNEL_STREAM_NULLMAP ? kind - KERNEL_STREAM_NULLMAP : kind;
-  return k == KERNEL_GENERIC_DBL || k == KERNEL_STREAM_PSEUDO || k == KERNEL_STREAM_DICTD || k == KERNEL_PFOR_DBL;
+    members[g].push_back((uint32_t)i);
+  }
+  auto slowness = [](uint32_t kind) {  // stream kinds by the time a 64 Ki-row block takes, longest first
+    switch (kind >= KERNEL_STREAM_NONE + KERNEL_STREAM_NULLMAP ? kind - KERNEL_STREAM_NULLMAP : kind) {
+      case KERNEL_STREAM_PSEUDO: return 0;
+      case KERNEL_STREAM_DICT_GLB: return 1;
+      case KERNEL_STREAM_DICT_LDS: return 2;
+      case KERNEL_STREAM_ADD: return 3;
+      default: return 4;
+    }
+  };
+  std::vector<LaunchGroup> groups(keys.size());
+  for (size_t g = 0; g < keys.size(); g++) {
+    std::vector<uint32_t>& m = members[g];
+    LaunchGroup& lg = groups[g];
+    if (keys[g].kernel >= KERNEL_KINDS)
+      std::stable_sort(m.begin(), m.end(), [&](uint32_t a, uint32_t b) { return slowness(progs[a].kernel) < slowness(progs[b].kernel); });
+    else if (kernel_is_generic(keys[g].kernel))  // generic programs: the ones with the most tables first
+      std::stable_sort(m.begin(), m.end(), [&](uint32_t a, uint32_t b) { return progs[a].lds_bytes > progs[b].lds_bytes; });
+    lg.kernel = keys[g].kernel;
+    lg.threads = threads_of(progs[m[0]].kernel);
+    lg.count = m.size();
+    uint32_t last_kind = ~0u;
+    for (size_t j = 0; j < m.size(); j++) {
+      const uint32_t i = m[j], kind = progs[i].kernel;
+      lg.lds = std::max(lg.lds, progs[i].lds_bytes);
+      lg.weight += ((uint64_t)items[i].tuple_count * (kind_is_double(kind) ? 8 : 4) + 1) * launch_cost(kind, keys[g].per_cu);
+      if (kind != last_kind) {
+        lg.seg.first_block[lg.seg.n] = (uint32_t)j;
+        lg.seg.kind[lg.seg.n++] = kind >= KERNEL_STREAM_NONE + KERNEL_STREAM_NULLMAP && !kernel_is_generic(kind) ? kind - KERNEL_STREAM_NULLMAP : kind;
+        last_kind = kind;
+      }
+    }
+    lg.seg.first_block[lg.seg.n] = (uint32_t)m.size();
+    if (lg.seg.n == 1) lg.kernel = progs[m[0]].kernel;  // one kind only: its own kernel
+  }
+  std::vector<size_t> by_weight(groups.size());
+  for (size_t g = 0; g < groups.size(); g++) by_weight[g] = g;
+  std::stable_sort(by_weight.begin(), by_weight.end(), [&](size_t a, size_t b) { return groups[a].weight > groups[b].weight; });
+  lo.order.reserve(items.size());
+  for (size_t g : by_weight) {
+    groups[g].begin = lo.order.size();
+    for (uint32_t i : members[g])
+      lo.order.push_back(LaunchEntry{i, items[i].prog_off, items[i].prog_bytes, launch_entry_check(i, items[i].prog_off, items[i].prog_bytes)});
+    if (groups[g].kernel >= KERNEL_KINDS) stats.kernel_mask |= 1u << groups[g].kernel;
+    lo.launches.push_back(groups[g]);
+  }
+  stats.launches = (uint32_t)lo.launches.size();
 }
 
 // Uploads the built programs and work items of a plan.
@@ -380,8 +474,7 @@ btr_status finish_plan(btr_gpu_ctx* ctx, std::vector<WorkItem>& items, std::vect
   lay_out(items, progs, stats, lo);
   const uint32_t debug_flags = debug_flags_from_env();
   for (WorkItem& it : items) it.debug_flags = debug_flags;
-  memcpy(plan->kind_begin, lo.kind_begin, sizeof(lo.kind_begin));
-  memcpy(plan->kind_lds, lo.kind_lds, sizeof(lo.kind_lds));
+  plan->launches = lo.launches;
   const std::vector<uint8_t>& blob = lo.blob;
   const uint64_t scratch = lo.scratch;
   auto cleanup = [&](btr_status st) {
@@ -389,25 +482,34 @@ btr_status finish_plan(btr_gpu_ctx* ctx, std::vector<WorkItem>& items, std::vect
     return st;
   };
   if (blob.size() > 0xFFFFFFF0ull) return cleanup(fail(BTR_ERR_UNSUPPORTED, "plan programs exceed 4 GiB"));
-  // Launch order: the kind with the most decoded bytes first; it runs on the caller's stream, the
-  // others beside it on streams of the context. When the others are a few odd chunks (a column whose
-  // blocks almost all take one cascade) they are small side launches: raised wave priority, dispatched
-  // ahead of the main grid. When several kinds carry real shares of the work (a relation-level plan
-  // over many columns) the launches are simply spread over the context's lanes, longest first.
+  // The launch with the most decoded bytes comes first. When the others are a few odd chunks (a
+  // column whose blocks almost all take one cascade) it runs on the caller's stream and they are
+  // small side launches on lanes of the context: raised wave priority, dispatched ahead of the main
+  // grid. When several launches carry real shares of the work (a relation-level plan over many
+  // columns) every launch runs on a lane, the caller's stream only forks and joins: the four lanes
+  // were created one after the other and so sit on four different hardware queues, whichever of
+  // them the caller's stream shares. Launches are dealt to the lanes longest first, each to the lane
+  // with the least work so far.
   {
-    uint64_t weight[KERNEL_KINDS] = {};
-    for (size_t i = 0; i < items.size(); i++) weight[progs[i].kernel] += (uint64_t)items[i].tuple_count * (kind_is_double(progs[i].kernel) ? 8 : 4) + 1;
-    uint32_t n = 0;
-    for (uint32_t kind = 0; kind < KERNEL_KINDS; kind++)
-      if (lo.kind_begin[kind + 1] > lo.kind_begin[kind]) plan->launch_order[n++] = kind;
-    std::stable_sort(plan->launch_order, plan->launch_order + n, [&](uint32_t a, uint32_t b) { return weight[a] > weight[b]; });
-    plan->n_launches = n;
-    plan->main_kind = n ? plan->launch_order[0] : 0;
-    plan->balanced = n > 1 && weight[plan->launch_order[1]] * 16 >= weight[plan->launch_order[0]];
-    for (uint32_t j = 1; j < n; j++) plan->is_side[plan->launch_order[j]] = true;
-    if (n > 1 && !plan->balanced)
-      for (size_t i = 0; i < items.size(); i++)
-        if (progs[i].kernel != plan->main_kind) items[i].flags |= ITEM_SIDE_LAUNCH;
+    const size_t n = plan->launches.size();
+    plan->lane.assign(n, 0);
+    plan->done.assign(n, nullptr);
+    plan->go.assign(n, nullptr);
+    plan->balanced = n > 1 && plan->launches[1].weight * 16 >= plan->launches[0].weight;
+    if (plan->balanced) {
+      uint64_t load[kColumnLanes] = {};
+      for (size_t j = 0; j < n; j++) {
+        uint32_t best = 0;
+        for (uint32_t l = 1; l < kColumnLanes; l++)
+          if (load[l] < load[best]) best = l;
+        load[best] += plan->launches[j].weight;
+        plan->lane[j] = best + 1;
+      }
+    } else if (n > 1) {
+      const LaunchGroup& main = plan->launches[0];
+      for (size_t i = 0; i < items.size(); i++) items[i].flags |= ITEM_SIDE_LAUNCH;
+      for (size_t k = 0; k < main.count; k++) items[lo.order[main.begin + k].item].flags &= ~(uint32_t)ITEM_SIDE_LAUNCH;
+    }
   }
   hipError_t e;
   if (scratch) {
@@ -417,6 +519,18 @@ btr_status finish_plan(btr_gpu_ctx* ctx, std::vector<WorkItem>& items, std::vect
   for (size_t i = 0; i < items.size(); i++)
     items[i].scratch = progs[i].scratch_bytes ? (uint64_t)(uintptr_t)plan->d_scratch + items[i].scratch : 0;
   if ((debug_flags & 8) && !items.empty()) {
+    {  // the step kinds of the first item's program, in stamp order (stamp 3 follows the first of them)
+      const uint8_t* prog = blob.data() + items[0].prog_off;
+      ProgramHeader hdr;
+      memcpy(&hdr, prog, sizeof(hdr));
+      fprintf(stderr, "[btr debug] steps after the %u index walks (kind[*: runs on into the next]):", hdr.n_bp_steps);
+      for (uint32_t k = hdr.n_bp_steps; k < hdr.n_steps; k++) {
+        Step st;
+        memcpy(&st, prog + sizeof(hdr) + k * sizeof(Step), sizeof(st));
+        fprintf(stderr, " %u%s", st.kind, st.no_barrier ? "*" : "");
+      }
+      fprintf(stderr, "\n");
+    }
     if ((e = hipMalloc((void**)&plan->d_debug, items.size() * kDebugSlots * 4)) != hipSuccess)
       return cleanup(hip_fail(e, "hipMalloc(debug)"));
     (void)hipMemset(plan->d_debug, 0, items.size() * kDebugSlots * 4);
@@ -437,14 +551,13 @@ btr_status finish_plan(btr_gpu_ctx* ctx, std::vector<WorkItem>& items, std::vect
       return cleanup(hip_fail(e, "hipMemcpy(programs)"));
     if ((e = hipMemset(plan->d_status, 0, items.size() * 4)) != hipSuccess)
       return cleanup(hip_fail(e, "hipMemset(status)"));
-    if (plan->n_launches > 1) {
+    if (plan->launches.size() > 1) {
       if ((e = hipEventCreateWithFlags(&plan->fork, hipEventDisableTiming)) != hipSuccess)
         return cleanup(hip_fail(e, "hipEventCreate"));
-      for (uint32_t kind = 0; kind < KERNEL_KINDS; kind++) {
-        if (!plan->is_side[kind]) continue;
-        if ((e = hipEventCreateWithFlags(&plan->side_done[kind], hipEventDisableTiming)) != hipSuccess)
+      for (size_t j = plan->balanced ? 0 : 1; j < plan->launches.size(); j++) {
+        if ((e = hipEventCreateWithFlags(&plan->done[j], hipEventDisableTiming)) != hipSuccess)
           return cleanup(hip_fail(e, "hipEventCreate"));
-        if ((e = hipEventCreateWithFlags(&plan->side_go[kind], hipEventDisableTiming)) != hipSuccess)
+        if (!plan->balanced && (e = hipEventCreateWithFlags(&plan->go[j], hipEventDisableTiming)) != hipSuccess)
           return cleanup(hip_fail(e, "hipEventCreate"));
       }
     }
@@ -524,6 +637,8 @@ const char* btr_kernel_name(uint32_t k) {
       "btr_decode_int_pfor_kernel", "btr_decode_dbl_pfor_kernel",
       "btr_stream_none_nm_kernel", "btr_stream_add_nm_kernel", "btr_stream_dict_lds_nm_kernel",
       "btr_stream_dict_glb_nm_kernel", "btr_stream_pseudo_nm_kernel", "btr_stream_dictd_nm_kernel"};
+  if (k == KERNEL_KINDS) return "btr_stream_mixed_kernel";
+  if (k == KERNEL_KINDS + 1) return "btr_stream_mixed_nm_kernel";
   return k < KERNEL_KINDS ? names[k] : nullptr;
 }
 
@@ -1039,10 +1154,10 @@ void btr_gpu_plan_destroy(btr_gpu_plan* plan) {
   if (plan->d_debug) (void)hipFree(plan->d_debug);
   if (plan->d_order) (void)hipFree(plan->d_order);
   if (plan->d_scratch) (void)hipFree(plan->d_scratch);
-  for (uint32_t kind = 0; kind < KERNEL_KINDS; kind++) {
-    if (plan->side_done[kind]) (void)hipEventDestroy(plan->side_done[kind]);
-    if (plan->side_go[kind]) (void)hipEventDestroy(plan->side_go[kind]);
-  }
+  for (hipEvent_t ev : plan->done)
+    if (ev) (void)hipEventDestroy(ev);
+  for (hipEvent_t ev : plan->go)
+    if (ev) (void)hipEventDestroy(ev);
   if (plan->fork) (void)hipEventDestroy(plan->fork);
   delete plan;
 }
@@ -1053,11 +1168,6 @@ btr_status btr_gpu_plan_stats(const btr_gpu_plan* plan, btr_plan_stats* out) {
   return BTR_OK;
 }
 
-static unsigned threads_of(uint32_t kind) {
-  return kind == KERNEL_STREAM_DICTD || kind == KERNEL_STREAM_DICTD + KERNEL_STREAM_NULLMAP ? kDictdThreads
-         : kernel_is_generic(kind)                                                         ? kBlockThreads
-                                                                                           : kStreamThreads;
-}
 using DecodeKernel = void (*)(const WorkItem*, const LaunchEntry*, const uint8_t*, uint32_t*);
 static DecodeKernel kernel_of(uint32_t kind) {
   static const DecodeKernel kernels[KERNEL_KINDS] = {btr_decode_int_kernel,      btr_decode_dbl_kernel,
@@ -1070,6 +1180,20 @@ static DecodeKernel kernel_of(uint32_t kind) {
                                                      btr_stream_pseudo_nm_kernel, btr_stream_dictd_nm_kernel};
   return kernels[kind];
 }
+// Enqueues one launch of a layout. `order` is the whole launch order on the device.
+static hipError_t enqueue_launch(const LaunchGroup& lg, hipStream_t on, const WorkItem* d_items, const LaunchEntry* d_order,
+                                 const uint8_t* d_programs, uint32_t* d_status) {
+  if (lg.kernel == kMixedStream)
+    hipLaunchKernelGGL(btr_stream_mixed_kernel, dim3((unsigned)lg.count), dim3(lg.threads), lg.lds, on, d_items,
+                       d_order + lg.begin, d_programs, d_status, lg.seg);
+  else if (lg.kernel == kMixedStreamNm)
+    hipLaunchKernelGGL(btr_stream_mixed_nm_kernel, dim3((unsigned)lg.count), dim3(lg.threads), lg.lds, on, d_items,
+                       d_order + lg.begin, d_programs, d_status, lg.seg);
+  else
+    hipLaunchKernelGGL(kernel_of(lg.kernel), dim3((unsigned)lg.count), dim3(lg.threads), lg.lds, on, d_items,
+                       d_order + lg.begin, d_programs, d_status);
+  return hipGetLastError();
+}
 
 btr_status btr_gpu_decode(btr_gpu_ctx* ctx, btr_gpu_plan* plan, void* hip_stream) {
   if (!ctx || !plan) return fail(BTR_ERR_INVALID_ARGUMENT, "null argument");
@@ -1077,33 +1201,34 @@ btr_status btr_gpu_decode(btr_gpu_ctx* ctx, btr_gpu_plan* plan, void* hip_stream
   DeviceGuard guard(plan->device);
   if (!guard.ok) return fail(BTR_ERR_DEVICE, "hipSetDevice failed");
   hipStream_t stream = (hipStream_t)hip_stream;
-  auto launch = [&](uint32_t kind, hipStream_t on) {
-    const size_t n = plan->kind_begin[kind + 1] - plan->kind_begin[kind];
-    hipLaunchKernelGGL(kernel_of(kind), dim3((unsigned)n), dim3(threads_of(kind)), plan->kind_lds[kind], on,
-                       plan->d_items, plan->d_order + plan->kind_begin[kind], plan->d_programs, plan->d_status);
-    return hipGetLastError();
+  auto launch = [&](size_t j, hipStream_t on) {
+    return enqueue_launch(plan->launches[j], on, plan->d_items, plan->d_order, plan->d_programs, plan->d_status);
   };
-  if (plan->n_launches <= 1) {
-    if (plan->n_launches) HIP_TRY(launch(plan->main_kind, stream));
+  const size_t n = plan->launches.size();
+  if (n <= 1) {
+    if (n) HIP_TRY(launch(0, stream));
     return BTR_OK;
   }
   std::lock_guard<std::recursive_mutex> lock(ctx->streams_mutex);
   HIP_TRY(hipEventRecord(plan->fork, stream));
   if (plan->balanced) {
-    // several large launches: the longest on the caller's stream, the others on the context's lanes
-    HIP_TRY(launch(plan->main_kind, stream));
-    for (uint32_t j = 1; j < plan->n_launches; j++) {
-      const uint32_t kind = plan->launch_order[j];
-      hipStream_t on = ctx->lane[(j - 1) % kColumnLanes];
-      if (on == stream) {  // the caller decodes on one of the lanes (btr_gpu_decode_columns)
-        HIP_TRY(launch(kind, stream));
-        continue;
+    // several large launches, all of them on lanes of the context; one join per lane, behind its last launch
+    bool forked[kColumnLanes] = {};
+    size_t last_on[kColumnLanes];
+    for (size_t j = 0; j < n; j++) last_on[plan->lane[j] - 1] = j;
+    for (size_t j = 0; j < n; j++) {
+      const uint32_t l = plan->lane[j] - 1;
+      hipStream_t on = ctx->lane[l];
+      if (on != stream && !forked[l]) {  // (the caller may be decoding on one of the lanes: btr_gpu_decode_columns)
+        HIP_TRY(hipStreamWaitEvent(on, plan->fork, 0));
+        forked[l] = true;
       }
-      HIP_TRY(hipStreamWaitEvent(on, plan->fork, 0));
-      HIP_TRY(launch(kind, on));
-      HIP_TRY(hipEventRecord(plan->side_done[kind], on));
-      HIP_TRY(hipStreamWaitEvent(stream, plan->side_done[kind], 0));
+      HIP_TRY(launch(j, on));
+      if (on != stream && last_on[l] == j) HIP_TRY(hipEventRecord(plan->done[j], on));
     }
+    for (size_t j = 0; j < n; j++)
+      if (ctx->lane[plan->lane[j] - 1] != stream && last_on[plan->lane[j] - 1] == j)
+        HIP_TRY(hipStreamWaitEvent(stream, plan->done[j], 0));
     return BTR_OK;
   }
   // The small launches fork from the caller's stream first, the main one follows on the stream
@@ -1111,17 +1236,16 @@ btr_status btr_gpu_decode(btr_gpu_ctx* ctx, btr_gpu_plan* plan, void* hip_stream
   // side stream records right before its own launch: the few workgroups of a side launch (which may
   // need more LDS than the main launch leaves free on any CU) are then dispatched onto an empty GPU
   // instead of queueing for a slot until the main grid has been handed out.
-  for (uint32_t j = 1; j < plan->n_launches; j++) {
-    const uint32_t kind = plan->launch_order[j];
+  for (size_t j = 1; j < n; j++) {
     hipStream_t on = ctx->lane[ctx->next_side++ % kColumnLanes];
     HIP_TRY(hipStreamWaitEvent(on, plan->fork, 0));
-    HIP_TRY(hipEventRecord(plan->side_go[kind], on));
-    HIP_TRY(launch(kind, on));
-    HIP_TRY(hipEventRecord(plan->side_done[kind], on));
+    HIP_TRY(hipEventRecord(plan->go[j], on));
+    HIP_TRY(launch(j, on));
+    HIP_TRY(hipEventRecord(plan->done[j], on));
   }
-  for (uint32_t j = 1; j < plan->n_launches; j++) HIP_TRY(hipStreamWaitEvent(stream, plan->side_go[plan->launch_order[j]], 0));
-  HIP_TRY(launch(plan->main_kind, stream));
-  for (uint32_t j = 1; j < plan->n_launches; j++) HIP_TRY(hipStreamWaitEvent(stream, plan->side_done[plan->launch_order[j]], 0));
+  for (size_t j = 1; j < n; j++) HIP_TRY(hipStreamWaitEvent(stream, plan->go[j], 0));
+  HIP_TRY(launch(0, stream));
+  for (size_t j = 1; j < n; j++) HIP_TRY(hipStreamWaitEvent(stream, plan->done[j], 0));
   return BTR_OK;
 }
 
@@ -1198,13 +1322,8 @@ btr_status btr_gpu_decode_chunks_noalloc(btr_gpu_ctx* ctx, const btr_chunk_desc*
   const LaunchEntry* d_order = reinterpret_cast<const LaunchEntry*>(dev + kStaticOrderOff);
   uint32_t* d_status = reinterpret_cast<uint32_t*>(dev + kStaticStatusOff);
   const uint8_t* d_programs = dev + kStaticProgOff;
-  for (uint32_t kind = 0; kind < KERNEL_KINDS; kind++) {  // one launch per kernel kind, back to back on the stream
-    const size_t cnt = lo.kind_begin[kind + 1] - lo.kind_begin[kind];
-    if (!cnt) continue;
-    hipLaunchKernelGGL(kernel_of(kind), dim3((unsigned)cnt), dim3(threads_of(kind)), lo.kind_lds[kind], stream, d_items,
-                       d_order + lo.kind_begin[kind], d_programs, d_status);
-    HIP_TRY(hipGetLastError());
-  }
+  for (const LaunchGroup& lg : lo.launches)  // back to back on the stream
+    HIP_TRY(enqueue_launch(lg, stream, d_items, d_order, d_programs, d_status));
   if (!status_or) return BTR_OK;
   HIP_TRY(hipStreamSynchronize(stream));
   uint32_t words[kStaticMaxChunks];
@@ -1253,14 +1372,14 @@ btr_status btr_gpu_plan_check(btr_gpu_ctx* ctx, btr_gpu_plan* plan, void* hip_st
     fprintf(stderr, "\n[btr debug] item start times (us), deciles:");
     for (int d = 0; d <= 10 && !starts.empty(); d++) fprintf(stderr, " %.1f", starts[(starts.size() - 1) * d / 10] * 0.01);
     fprintf(stderr, "\n");
-    for (uint32_t kind = 0; kind < KERNEL_KINDS; kind++) {
-      if (plan->kind_begin[kind + 1] == plan->kind_begin[kind]) continue;
+    for (const LaunchGroup& lg : plan->launches) {
       int per_cu = 0;
-      const int threads = (int)threads_of(kind);
-      (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kernel_of(kind)), threads,
-                                                         plan->kind_lds[kind]);
-      fprintf(stderr, "[btr debug] %s: %u bytes of LDS, %d workgroups per CU\n", btr_kernel_name(kind),
-              plan->kind_lds[kind], per_cu);
+      const void* fn = lg.kernel == kMixedStream     ? reinterpret_cast<const void*>(btr_stream_mixed_kernel)
+                       : lg.kernel == kMixedStreamNm ? reinterpret_cast<const void*>(btr_stream_mixed_nm_kernel)
+                                                     : reinterpret_cast<const void*>(kernel_of(lg.kernel));
+      (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, (int)lg.threads, lg.lds);
+      fprintf(stderr, "[btr debug] %s: %zu workgroups, %u bytes of LDS, %d workgroups per CU\n", btr_kernel_name(lg.kernel),
+              lg.count, lg.lds, per_cu);
     }
   }
   uint32_t any = 0;

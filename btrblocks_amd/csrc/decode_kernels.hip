@@ -3503,3 +3503,40 @@ BTR_STREAM_NULLMAP_KERNEL(btr_stream_dict_glb_nm_kernel, kStreamThreads, (stream
 BTR_STREAM_NULLMAP_KERNEL(btr_stream_pseudo_nm_kernel, kStreamThreads, (stream_pseudo_block<true>))
 BTR_STREAM_NULLMAP_KERNEL(btr_stream_dictd_nm_kernel, kDictdThreads, (stream_dictd_block<true>))
 #undef BTR_STREAM_NULLMAP_KERNEL
+
+// One launch over chunks of several 512-thread stream kinds (a relation's FOR, DICT and
+// Pseudodecimal columns; a column whose blocks took different cascades): every workgroup runs the
+// block routine of its segment's kind. All of these kinds run four workgroups per CU whatever their
+// LDS need, so sharing a launch (and its LDS size, the largest of them) costs none of them occupancy,
+// while one launch instead of several leaves no gaps between kernels of one hardware queue.
+namespace {
+template <bool WITH_NULLMAP>
+__device__ __forceinline__ void stream_mixed_block(const WorkItem* __restrict__ items, const LaunchEntry* __restrict__ order,
+                                                   const u8* __restrict__ programs, u32* __restrict__ status,
+                                                   const LaunchSegments& seg) {
+  u32 kind = seg.kind[0];
+#pragma unroll
+  for (u32 k = 1; k < kMaxSegments; k++)
+    if (k < seg.n && blockIdx.x >= seg.first_block[k]) kind = seg.kind[k];
+  switch (uniform(kind)) {
+    case KERNEL_STREAM_NONE: stream_block<PS_NONE, WITH_NULLMAP>(items, order, programs, status); break;
+    case KERNEL_STREAM_ADD: stream_block<PS_ADD, WITH_NULLMAP>(items, order, programs, status); break;
+    case KERNEL_STREAM_DICT_LDS: stream_block<PS_DICT_LDS, WITH_NULLMAP>(items, order, programs, status); break;
+    case KERNEL_STREAM_DICT_GLB: stream_block<PS_DICT_GLB, WITH_NULLMAP>(items, order, programs, status); break;
+    case KERNEL_STREAM_PSEUDO: stream_pseudo_block<WITH_NULLMAP>(items, order, programs, status); break;
+    default:  // not a kind this kernel decodes: the launch was put together wrongly
+      if (threadIdx.x == 0) atomicOr(status, (u32)ST_PROGRAM);
+      break;
+  }
+}
+}  // namespace
+extern "C" __global__ void __launch_bounds__(kStreamThreads) __attribute__((amdgpu_waves_per_eu(8, 8)))
+btr_stream_mixed_kernel(const WorkItem* __restrict__ items, const LaunchEntry* __restrict__ order,
+                        const u8* __restrict__ programs, u32* __restrict__ status, const LaunchSegments seg) {
+  stream_mixed_block<false>(items, order, programs, status, seg);
+}
+extern "C" __global__ void __launch_bounds__(kStreamThreads) __attribute__((amdgpu_waves_per_eu(8, 8)))
+btr_stream_mixed_nm_kernel(const WorkItem* __restrict__ items, const LaunchEntry* __restrict__ order,
+                           const u8* __restrict__ programs, u32* __restrict__ status, const LaunchSegments seg) {
+  stream_mixed_block<true>(items, order, programs, status, seg);
+}

@@ -249,13 +249,8 @@ btr_status btr_gpu_pipeline_submit(btr_gpu_pipeline* p, const btr_part_job* job)
   const WorkItem* d_items = reinterpret_cast<const WorkItem*>(s.d_arena);
   const LaunchEntry* d_order = reinterpret_cast<const LaunchEntry*>(s.d_arena + order_off);
   uint32_t* d_status = reinterpret_cast<uint32_t*>(s.d_arena + status_off);
-  for (uint32_t kind = 0; kind < KERNEL_KINDS; kind++) {
-    const size_t cnt = lo.kind_begin[kind + 1] - lo.kind_begin[kind];
-    if (!cnt) continue;
-    hipLaunchKernelGGL(kernel_of(kind), dim3((unsigned)cnt), dim3(threads_of(kind)), lo.kind_lds[kind], p->s_dec, d_items,
-                       d_order + lo.kind_begin[kind], s.d_arena + prog_off, d_status);
-    HIP_TRY(hipGetLastError());
-  }
+  for (const LaunchGroup& lg : lo.launches)
+    HIP_TRY(enqueue_launch(lg, p->s_dec, d_items, d_order, s.d_arena + prog_off, d_status));
   HIP_TRY(hipEventRecord(s.decode_done, p->s_dec));
   // ---- copy-out --------------------------------------------------------------------------------
   HIP_TRY(hipStreamWaitEvent(p->s_out, s.decode_done, 0));

@@ -143,7 +143,7 @@ struct WorkItem {
   uint32_t flags;        // ITEM_* bits
   uint64_t debug_buf;    // flag 8: kDebugSlots 100 MHz timestamps of this item
 };
-constexpr uint32_t kDebugSlots = 16;
+constexpr uint32_t kDebugSlots = 32;
 // One entry per workgroup of a launch, in launch order: which work item it decodes and where that
 // item's program lies. The program's place is repeated here so that a workgroup can start copying
 // its program as soon as it has its entry, beside the load of the work item (two dependent memory
@@ -199,6 +199,15 @@ enum : uint32_t {
 constexpr bool kernel_is_generic(uint32_t k) {
   return k <= KERNEL_GENERIC_DBL || k == KERNEL_PFOR_INT || k == KERNEL_PFOR_DBL;
 }
+
+// A launch may decode chunks of several stream kinds: its workgroups are grouped into segments of
+// one kind each, and a workgroup finds its kind from its index (the mixed stream kernels).
+constexpr uint32_t kMaxSegments = 6;
+struct LaunchSegments {
+  uint32_t n;
+  uint32_t first_block[kMaxSegments + 1];  // first_block[n] = workgroups of the launch
+  uint32_t kind[kMaxSegments];             // KERNEL_STREAM_* (without the nullmap offset)
+};
 
 constexpr uint32_t kBlockThreads = 256;
 constexpr uint32_t kStreamRingBytes = 16 * 1024;  // LDS ring of the streamed root step (4 batches of 1024 words)

@@ -36,7 +36,7 @@ try:  # the counter runs decode more columns than the default line (PFOR, fill, 
         cols.setdefault(name, c)
 except (OSError, IndexError, KeyError, ValueError):
     pass
-summary = {"unit": "bytes", "convention": "2 * FETCH_SIZE * 1024 + WRITE_SIZE * 1024 per launch", "bytes_per_launch": {},
+summary = {"tag": tag, "unit": "bytes", "convention": "2 * FETCH_SIZE * 1024 + WRITE_SIZE * 1024 per launch", "bytes_per_launch": {},
            "detail": {}}
 # The generic integer kernel decodes three columns in the counter runs (rle, onevalue, uncompressed), launched
 # in that order each step: split its launches by position.
