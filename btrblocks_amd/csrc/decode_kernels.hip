@@ -1003,7 +1003,17 @@ __device__ __forceinline__ u32x4 eval_int4_base(const IntEval& e, u32 i, __amdgp
 }
 
 constexpr u32 kUnroll4 = 2;
+// The decoded column is stored non-temporally. With ordinary write-back stores a launch that reads
+// little (a fill, run expansion) ends up to 18 % sooner, but its dirty lines are written back during
+// the launch behind it, which loses the same time: over a step the sum is the same, and with several
+// launches beside each other (a relation-level plan) write-back stores were 2-3 % slower.
+#ifdef BTR_PLAIN_STORES  // experiment builds only
+constexpr int kStoreNt = 0;
+#define BTR_NT_STORE(v, p) (*(p) = (v))
+#else
 constexpr int kStoreNt = 2;  // cache policy bit of buffer stores: non-temporal
+#define BTR_NT_STORE(v, p) __builtin_nontemporal_store(v, p)
+#endif
 
 template <u32 BASE, u32 PS, bool TAB_LDS = false>
 __device__ __forceinline__ void mat_int4(const Ctx& c, const IntEval& e, u32* __restrict__ dst, u32 count) {
@@ -1038,7 +1048,7 @@ __device__ __forceinline__ void mat_int4(const Ctx& c, const IntEval& e, u32* __
       const u32 i = base + (u * kBlockThreads + tid) * 4;
       // non-temporal: the decoded column is written once and not read back by this kernel; keeping
       // it out of the caches also keeps its write-back out of the next launch's time
-      if (!PARTIAL || i < quads) __builtin_nontemporal_store(v[u], reinterpret_cast<u32x4*>(dst + i));
+      if (!PARTIAL || i < quads) BTR_NT_STORE(v[u], reinterpret_cast<u32x4*>(dst + i));
     }
   };
   for (u32 base = 0; base < whole; base += kRowsPerIter) iteration(base, std::false_type{});
@@ -2065,7 +2075,7 @@ __device__ __forceinline__ void mat_dbl2(const Ctx& c, const DblEval& e, u64* __
 #pragma unroll
     for (u32 u = 0; u < kUnrollHere; u++) {
       const u32 i = base + (u * kBlockThreads + tid) * 2;
-      if (!PARTIAL || i < pairs) __builtin_nontemporal_store(v[u], reinterpret_cast<u64x2*>(dst + i));
+      if (!PARTIAL || i < pairs) BTR_NT_STORE(v[u], reinterpret_cast<u64x2*>(dst + i));
     }
   };
   for (u32 base = 0; base < whole; base += kRowsPerIter) iteration(base, std::false_type{});
@@ -2159,8 +2169,8 @@ __device__ __forceinline__ void mat_pseudo_rle4(const Ctx& c, const DblEval& e, 
     if (first < quads) {
       u64x2 lo, hi;
       lo.x = out[0], lo.y = out[1], hi.x = out[2], hi.y = out[3];
-      __builtin_nontemporal_store(lo, reinterpret_cast<u64x2*>(dst + i));
-      __builtin_nontemporal_store(hi, reinterpret_cast<u64x2*>(dst + i + 2));
+      BTR_NT_STORE(lo, reinterpret_cast<u64x2*>(dst + i));
+      BTR_NT_STORE(hi, reinterpret_cast<u64x2*>(dst + i + 2));
     }
   };
   for (u32 base = 0; base < quads; base += kBlockThreads * 8) {
@@ -3076,7 +3086,7 @@ __device__ __forceinline__ void write_nullmap(const Ctx& c, const Step& s) {
     u32x4 v;
     v.x = v.y = v.z = v.w = fill;
     for (u32 q = threadIdx.x; q < body; q += THREADS)
-      __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(c.nullmap + h + 16 * q));
+      BTR_NT_STORE(v, reinterpret_cast<u32x4*>(c.nullmap + h + 16 * q));
     for (u32 i = threadIdx.x; i < h; i += THREADS) c.nullmap[i] = (u8)fill;
     for (u32 i = h + 16 * body + threadIdx.x; i < n; i += THREADS) c.nullmap[i] = (u8)fill;
     return;
@@ -3093,7 +3103,7 @@ __device__ __forceinline__ void write_nullmap(const Ctx& c, const Step& s) {
       v.y = (((bits >> 4) & 15) * 0x00204081u) & 0x01010101u;
       v.z = (((bits >> 8) & 15) * 0x00204081u) & 0x01010101u;
       v.w = (((bits >> 12) & 15) * 0x00204081u) & 0x01010101u;
-      __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(c.nullmap + 16 * q));
+      BTR_NT_STORE(v, reinterpret_cast<u32x4*>(c.nullmap + 16 * q));
     }
     done = body * 16;
   }
