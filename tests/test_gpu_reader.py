@@ -285,3 +285,53 @@ def test_columns_decoded_beside_each_other_match_one_after_the_other(gpu_ctx):
             assert p.check(stream) == 0
         for r, w in zip(readers, want):
             assert torch.equal(r.d_out, w)
+
+
+@pytest.mark.parametrize("nulls", [None, 0.9])
+def test_relation_level_plan_over_all_columns(gpu_ctx, nulls):
+    """One plan over the chunks of every column of a relation (decompression-speed.cpp:45-58 hands all
+    columns x parts x chunks to one scheduler): its launches are kernels and occupancy classes, not
+    columns; the FOR, DICT and Pseudodecimal chunks share one mixed launch. Decoded twice back to
+    back; every chunk bit for bit against the oracle."""
+    import torch
+    from btrblocks_amd import api, _native as N
+    rows = 5 * 65536 + 1234  # ragged last block
+    cols = [("int_rle", "rle(bp,bp)"), ("int_dict", "dict(bp)"), ("int_for", "for(bp)"), ("int_rle_pool", "rle(dict(bp),bp)"),
+            ("int_outliers", "pfor"), ("int_constant", "onevalue"), ("int_frequency_pool", "frequency(dict(bp))"),
+            ("double_decimal", "pseudodecimal(bp,bp,uncompressed)"),
+            ("double_decimal_runs", "pseudodecimal(rle(dict(bp),bp),rle(bp,bp),uncompressed)"),
+            ("double_dict", "dict(bp)"), ("double_runs", "rle(uncompressed,bp)")]
+    readers = []
+    for k, (gen, spec) in enumerate(cols):
+        values = getattr(synth, gen)(rows)
+        nm = None if nulls is None else synth.random_nullmap(rows, nulls, seed=20 + k)
+        readers.append(B.BtrReader(B.compress_column(values, nm, spec, threads=2), ctx=gpu_ctx))
+    want_nm = nulls is not None
+    for r in readers:
+        r.plan(None, want_nm)  # allocates the nullmap outputs
+    descs = [r._desc(i, want_nm) for r in readers for i in range(len(r.chunks))]
+    plan = api.DecodePlan(gpu_ctx, descs, keepalive=tuple(readers))
+    st = plan.stats
+    assert st.chunks == len(descs) and st.launches >= 4 and st.launches < len(cols)
+    mixed_bit = 16 + (1 if want_nm else 0)
+    assert st.kernel_mask >> mixed_bit & 1, "FOR, DICT and Pseudodecimal chunks share the mixed stream launch"
+    stream = api.current_stream_ptr()
+    for _ in range(2):
+        for r in readers:
+            r.d_out.zero_()
+        plan.decode(stream)
+        plan.check(stream)
+        torch.cuda.synchronize()
+        for r in readers:
+            got = r.d_out.cpu().numpy()
+            got_nm = r.d_nullmap.cpu().numpy() if want_nm else None
+            for i, (o, n) in enumerate(r.chunks):
+                chunk = r.image[o:o + n]
+                want, oracle_nm = pyoracle.decode_chunk(chunk, want_nullmap=True)
+                want = want.view(np.uint8)
+                lo = int(r.out_offsets[i])
+                np.testing.assert_array_equal(got[lo:lo + want.size], want)
+                if want_nm:
+                    r0 = int(r.row_offsets[i])
+                    np.testing.assert_array_equal(got_nm[r0:r0 + oracle_nm.size], oracle_nm)
+    plan.close()
