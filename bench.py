@@ -500,13 +500,24 @@ def run_rank(args):
                 kern = per_column[cols[dom]["name"]]["kernels"][0]
                 tag = summary.get("tag", "untagged")
                 detail = summary.get("detail", {}).get(kern)
-                if detail is not None and detail.get("algorithmic_bytes") == dom_alg:
+                rel_cols = summary.get("relation", {}).get("columns", {})
+                if relation and cols[dom]["name"] in rel_cols:  # the counter passes of the mixed relation, per column
+                    detail = dict(rel_cols[cols[dom]["name"]], column=cols[dom]["name"])
+                    tag = summary["relation"].get("tag", tag)
+                    if detail.get("algorithmic_bytes") == dom_alg:
+                        traffic = detail["read_bytes"] + detail["write_bytes"]
+                        traffic_source = (f"profiles/pmc_traffic.json ({tag}, relation): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                                          "passes of this column's launch")
+                        detail = None
+                if traffic is not None:
+                    pass
+                elif detail is not None and detail.get("algorithmic_bytes") == dom_alg:
                     traffic = summary["bytes_per_launch"][kern]
                     traffic_source = f"profiles/pmc_traffic.json ({tag}): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload"
                 elif detail is not None:
                     traffic = int(round(detail["traffic_over_algorithmic"] * dom_alg))
                     traffic_source = (f"profiles/pmc_traffic.json ({tag}): {kern} moved {detail['traffic_over_algorithmic']} x its "
-                                      f"algorithmic bytes in the counter passes of column '{detail['column']}' at 4096 blocks; "
+                                      f"algorithmic bytes in the counter passes of column '{detail['column']}' at 4096 blocks per column; "
                                       "that ratio times this launch's algorithmic bytes")
             except Exception:
                 traffic, traffic_source = None, None
