@@ -262,6 +262,8 @@ def parse_args():
     ap.add_argument("--beside-leg", action="store_true",
                     help="N = 1: after the timed region, time the same step with the columns beside each other as well "
                          "(columns_beside_each_other; its launches overlap, so leave it out of profiled runs)")
+    ap.add_argument("--no-plan-leg", action="store_true",
+                    help="N = 1: skip the secondary leg that decodes the step through one plan over all columns")
     ap.add_argument("--serial", action="store_true", help="N > 1: one column launch after the other, as at N = 1")
     ap.add_argument("--per-column-plans", action="store_true",
                     help="mixed relation: one plan per column, decoded beside each other, instead of ONE plan over the "
@@ -437,6 +439,23 @@ def run_rank(args):
         beside_ms = (time.perf_counter() - t2) / args.steps * 1e3
         for p in plans:
             p.check(stream)
+    one_plan_ms = None
+    if world == 1 and rel_plan is None and not concurrent and len(readers) > 1 and not args.no_plan_leg:
+        # secondary figure: the same step through ONE plan over the chunks of all columns (launches per kernel,
+        # beside each other); its launches overlap, so it is not the timed region of this line
+        descs = [r._desc(i, want_nm) for r in readers for i in range(len(r.chunks))]
+        one_plan = api.DecodePlan(ctx, descs, keepalive=tuple(readers))
+        for _ in range(2):
+            one_plan.decode(stream)
+        barrier()
+        t2 = time.perf_counter()
+        for _ in range(args.steps):
+            one_plan.decode(stream)
+        barrier()
+        one_plan_ms = (time.perf_counter() - t2) / args.steps * 1e3
+        one_plan.check(stream)
+        one_plan_launches = int(one_plan.stats.launches)
+        one_plan.close()
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -582,6 +601,12 @@ def run_rank(args):
                 "threads": host_threads,
             },
         }
+        if one_plan_ms is not None:
+            line["one_plan_over_all_columns"] = {"ms_per_step": round(one_plan_ms, 4), "GBps": round(total_out / one_plan_ms / 1e6, 2),
+                                                 "launches_per_step": one_plan_launches,
+                                                 "what": "the same step through one btr_gpu_plan over the chunks of all columns "
+                                                         "(launches per kernel, beside each other), timed after the timed region; "
+                                                         "not the value of this line"}
         if beside_ms is not None:
             line["columns_beside_each_other"] = {"ms_per_step": round(beside_ms, 4),
                                                  "GBps": round(total_out / beside_ms / 1e6, 2),
