@@ -316,11 +316,22 @@ def test_relation_level_plan_over_all_columns(gpu_ctx, nulls):
     mixed_bit = 16 + (1 if want_nm else 0)
     assert st.kernel_mask >> mixed_bit & 1, "FOR, DICT and Pseudodecimal chunks share the mixed stream launch"
     stream = api.current_stream_ptr()
-    for _ in range(2):
+    # two more plans, each over half of the columns: decoded beside each other below (plans with
+    # several large launches on the lanes btr_gpu_decode_columns itself decodes on)
+    half = len(readers) // 2
+    halves = [api.DecodePlan(gpu_ctx, [r._desc(i, want_nm) for r in part for i in range(len(r.chunks))], keepalive=tuple(part))
+              for part in (readers[:half], readers[half:])]
+    assert all(h.stats.launches > 1 for h in halves)
+    for attempt in range(3):
         for r in readers:
             r.d_out.zero_()
-        plan.decode(stream)
-        plan.check(stream)
+        if attempt < 2:
+            plan.decode(stream)
+            plan.check(stream)
+        else:
+            api.decode_columns(gpu_ctx, halves, stream)
+            for h in halves:
+                h.check(stream)
         torch.cuda.synchronize()
         for r in readers:
             got = r.d_out.cpu().numpy()
@@ -335,3 +346,5 @@ def test_relation_level_plan_over_all_columns(gpu_ctx, nulls):
                     r0 = int(r.row_offsets[i])
                     np.testing.assert_array_equal(got_nm[r0:r0 + oracle_nm.size], oracle_nm)
     plan.close()
+    for h in halves:
+        h.close()
