@@ -613,6 +613,20 @@ def run_rank(args):
                                                  "what": "the same step through btr_gpu_decode_columns; not the value of this line"}
         if world == 1 and not args.no_pipeline:
             line["host"]["pipeline"] = pipeline_rate(ctx, cols)
+        if world > 1:
+            # the same relation on ONE GPU, from the tracked profile run of `bench.py --relation` (the N = 1 default of
+            # this script is another workload, configs 2 + 3): the figure a strong-scaling efficiency is taken against
+            import glob
+            for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_config4_bench.json")), reverse=True):
+                try:
+                    one = json.load(open(path))
+                    if one.get("n_gpus") == 1 and one["config"]["rows"] == args.rows and \
+                            one["config"]["total_output_bytes"] == int(total_out):
+                        line["same_relation_on_one_gpu"] = {"value": one["value"], "unit": "GB/s", "ms_per_step": one["ms_per_step"],
+                                                            "source": "profiles/" + os.path.basename(path)}
+                        break
+                except Exception:
+                    continue
         if rel_plan is not None:
             line["relation_plan"] = {"chunks": int(rel_stats.chunks), "launches_per_step": int(rel_stats.launches),
                                      "kernels": kernel_names(rel_stats.kernel_mask), "plan_s": round(t_rel_plan, 3),
