@@ -375,7 +375,7 @@ def run_rank(args):
     rel_plan = None
     if relation and not args.serial and not args.concurrent and not args.per_column_plans and len(readers) > 1:
         t0 = time.time()
-        descs = [r._desc(i, want_nm) for r in readers for i in range(len(r.chunks))]
+        descs = [r.chunk_desc(i, want_nm) for r in readers for i in range(len(r.chunks))]
         rel_plan = api.DecodePlan(ctx, descs, keepalive=tuple(readers))
         t_rel_plan = time.time() - t0
         rel_stats = rel_plan.stats
@@ -443,7 +443,7 @@ def run_rank(args):
     if world == 1 and rel_plan is None and not concurrent and len(readers) > 1 and not args.no_plan_leg:
         # secondary figure: the same step through ONE plan over the chunks of all columns (launches per kernel,
         # beside each other); its launches overlap, so it is not the timed region of this line
-        descs = [r._desc(i, want_nm) for r in readers for i in range(len(r.chunks))]
+        descs = [r.chunk_desc(i, want_nm) for r in readers for i in range(len(r.chunks))]
         one_plan = api.DecodePlan(ctx, descs, keepalive=tuple(readers))
         for _ in range(2):
             one_plan.decode(stream)

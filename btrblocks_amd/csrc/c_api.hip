@@ -150,6 +150,7 @@ namespace {
 // Kernel of a launch: a kernel kind, or one of the two mixed stream kernels.
 constexpr uint32_t kMixedStream = KERNEL_KINDS, kMixedStreamNm = KERNEL_KINDS + 1;
 // One kernel launch: the entries [begin, begin + count) of the launch order.
+static_assert(kMaxSegments >= 5, "a mixed launch holds up to five stream kinds");
 struct LaunchGroup {
   uint32_t kernel = 0;   // kernel kind, kMixedStream or kMixedStreamNm
   uint32_t threads = 0;  // workgroup size

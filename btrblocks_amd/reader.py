@@ -60,7 +60,9 @@ class BtrReader:
         return self.getSchemeDescription(index).split("(")[0]
 
     # ---- decode ----------------------------------------------------------------------------
-    def _desc(self, index, with_nullmap):
+    def chunk_desc(self, index, with_nullmap=False):
+        """btr_chunk_desc of chunk `index` (compressed bytes in this reader's device image, output in its
+        device column): for plans over the chunks of several readers."""
         o, n = self.chunks[index]
         d = N.ChunkDesc()
         d.host_src = self.image.ctypes.data + o
@@ -70,6 +72,8 @@ class BtrReader:
         d.dst_bytes = self.infos[index].decoded_bytes
         d.dev_nullmap_dst = (self.d_nullmap.data_ptr() + int(self.row_offsets[index])) if with_nullmap else None
         return d
+
+    _desc = chunk_desc
 
     def plan(self, indices=None, with_nullmap=False):
         """Decode plan over the given chunks (all by default); cached."""
@@ -84,7 +88,7 @@ class BtrReader:
                     self.d_out.numel(), self.d_nullmap.data_ptr() if with_nullmap else None,
                     self.d_nullmap.numel() if with_nullmap else 0, keepalive=(self.d_image, self.d_out, self.d_nullmap))
             else:
-                self._plans[key] = api.DecodePlan(self.ctx, [self._desc(i, with_nullmap) for i in indices])
+                self._plans[key] = api.DecodePlan(self.ctx, [self.chunk_desc(i, with_nullmap) for i in indices])
         return self._plans[key]
 
     def readColumn(self, index, with_bitmap=False):

@@ -171,7 +171,12 @@ typedef struct btr_chunk_desc {
 
 /* Builds the device-resident decode plan for n chunks: the counterpart of constructing
  * BtrReader objects over column part images (BtrReader.cpp:12-15) - parsing, validation and
- * table placement happen here, not in btr_gpu_decode. */
+ * table placement happen here, not in btr_gpu_decode.
+ * The chunks may belong to any number of columns: a plan over all columns of a relation (or of a
+ * rank's block range of it) is how tools/conversion/decompression-speed.cpp:45-58 hands every
+ * column x part x chunk to one scheduler. Such a plan launches one kernel per kernel kind and
+ * occupancy class, not one per column, beside each other on the caller's stream and streams of
+ * the context. */
 btr_status btr_gpu_plan_create(btr_gpu_ctx* ctx, const btr_chunk_desc* chunks, size_t n, btr_gpu_plan** out);
 
 /* Plan over chunks [first_chunk, first_chunk + chunk_count) of a column part image resident on the
@@ -221,7 +226,8 @@ typedef struct btr_plan_stats {
   uint64_t scratch_bytes;    /* HBM scratch for tables that did not fit in LDS                  */
   uint32_t max_lds_bytes;    /* dynamic LDS per workgroup                                       */
   uint32_t max_depth;
-  uint32_t kernel_mask;      /* bit k set: the plan launches kernel k (see btr_kernel_name)     */
+  uint32_t kernel_mask;      /* bit k set: chunks of the plan are decoded by kernel k (btr_kernel_name);
+                                bits 16 and 17: stream chunks of several kinds share a mixed launch */
   uint32_t launches;         /* kernel launches per btr_gpu_decode                              */
   double compile_seconds;    /* host time of the header walk + program compilation              */
   double upload_seconds;     /* host time of laying out and uploading programs and work items   */

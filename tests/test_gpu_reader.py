@@ -309,7 +309,7 @@ def test_relation_level_plan_over_all_columns(gpu_ctx, nulls):
     want_nm = nulls is not None
     for r in readers:
         r.plan(None, want_nm)  # allocates the nullmap outputs
-    descs = [r._desc(i, want_nm) for r in readers for i in range(len(r.chunks))]
+    descs = [r.chunk_desc(i, want_nm) for r in readers for i in range(len(r.chunks))]
     plan = api.DecodePlan(gpu_ctx, descs, keepalive=tuple(readers))
     st = plan.stats
     assert st.chunks == len(descs) and st.launches >= 4 and st.launches < len(cols)
@@ -319,7 +319,7 @@ def test_relation_level_plan_over_all_columns(gpu_ctx, nulls):
     # two more plans, each over half of the columns: decoded beside each other below (plans with
     # several large launches on the lanes btr_gpu_decode_columns itself decodes on)
     half = len(readers) // 2
-    halves = [api.DecodePlan(gpu_ctx, [r._desc(i, want_nm) for r in part for i in range(len(r.chunks))], keepalive=tuple(part))
+    halves = [api.DecodePlan(gpu_ctx, [r.chunk_desc(i, want_nm) for r in part for i in range(len(r.chunks))], keepalive=tuple(part))
               for part in (readers[:half], readers[half:])]
     assert all(h.stats.launches > 1 for h in halves)
     for attempt in range(3):
