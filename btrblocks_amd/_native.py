@@ -195,6 +195,7 @@ SIGNATURES = {
     "btr_gpu_decode_chunk_host": (C.c_int, [_P, _P, C.c_size_t, _P, C.c_size_t, _P]),
     "btr_gpu_plan_debug_access": (C.c_int, [_P, C.c_uint32, C.c_size_t, _P, C.c_size_t, C.c_int]),
     "btr_debug_launch_entry_check": (C.c_uint32, [C.c_uint32, C.c_uint32, C.c_uint32]),
+    "btr_debug_launch_layout": (C.c_int, [_P, C.c_size_t, C.c_char_p, C.c_size_t]),
     "btr_gpu_pipeline_create": (C.c_int, [_P, C.c_uint32, C.POINTER(_P)]),
     "btr_gpu_pipeline_destroy": (None, [_P]),
     "btr_gpu_pipeline_acquire": (C.c_int, [_P, C.c_size_t, C.POINTER(_P)]),

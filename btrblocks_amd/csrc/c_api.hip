@@ -1416,6 +1416,34 @@ uint32_t btr_debug_launch_entry_check(uint32_t item, uint32_t prog_off, uint32_t
   return launch_entry_check(item, prog_off, prog_bytes);
 }
 
+btr_status btr_debug_launch_layout(const btr_chunk_desc* chunks, size_t n, char* text, size_t text_bytes) {
+  if ((!chunks && n) || !text || !text_bytes) return fail(BTR_ERR_INVALID_ARGUMENT, "null argument");
+  std::vector<WorkItem> items;
+  std::vector<BuiltProgram> progs;
+  btr_plan_stats stats{};
+  Layout lo;
+  try {
+    const btr_status st = compile_chunks(chunks, n, items, progs, stats, 1);
+    if (st != BTR_OK) return st;
+    lay_out(items, progs, stats, lo);
+  } catch (const std::bad_alloc&) {
+    return fail(BTR_ERR_OUT_OF_MEMORY, "out of host memory while compiling the plan");
+  }
+  std::string out;
+  for (const LaunchGroup& lg : lo.launches) {
+    out += std::string(btr_kernel_name(lg.kernel)) + " threads=" + std::to_string(lg.threads) + " lds=" + std::to_string(lg.lds) +
+           " chunks=" + std::to_string(lg.count) + " [";
+    for (uint32_t k = 0; k < lg.seg.n; k++)
+      out += (k ? " " : "") + std::to_string(lg.seg.first_block[k]) + ":" + btr_kernel_name(lg.seg.kind[k]);
+    out += "] items=";
+    for (size_t k = 0; k < lg.count; k++) out += (k ? "," : "") + std::to_string(lo.order[lg.begin + k].item);
+    out += "\n";
+  }
+  if (out.size() + 1 > text_bytes) return fail(BTR_ERR_BUFFER_TOO_SMALL, "launch description needs " + std::to_string(out.size() + 1) + " bytes");
+  memcpy(text, out.c_str(), out.size() + 1);
+  return BTR_OK;
+}
+
 btr_status btr_gpu_plan_debug_access(btr_gpu_plan* plan, uint32_t region, size_t offset, void* host, size_t bytes,
                                      int write) {
   if (!plan || (!host && bytes)) return fail(BTR_ERR_INVALID_ARGUMENT, "null argument");

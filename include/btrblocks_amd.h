@@ -283,6 +283,13 @@ btr_status btr_gpu_plan_check(btr_gpu_ctx* ctx, btr_gpu_plan* plan, void* hip_st
 btr_status btr_gpu_plan_debug_access(btr_gpu_plan* plan, uint32_t region, size_t offset, void* host, size_t bytes,
                                      int write);
 uint32_t btr_debug_launch_entry_check(uint32_t item, uint32_t prog_off, uint32_t prog_bytes);
+/* Test hook that needs no device: compiles the chunks as btr_gpu_plan_create would (only host_src is
+ * read; dev_src and dev_dst are taken as addresses, nothing is launched) and describes the launches
+ * of the plan, one text line per launch in launch order:
+ *   "<kernel name> threads=<t> lds=<bytes> chunks=<n> [<first block>:<kernel kind name> ...] items=<i,j,...>"
+ * `text` receives at most text_bytes - 1 characters and a terminating 0; BTR_ERR_BUFFER_TOO_SMALL if
+ * the description does not fit. */
+btr_status btr_debug_launch_layout(const btr_chunk_desc* chunks, size_t n, char* text, size_t text_bytes);
 
 /* Host-in / host-out decode of one chunk: BtrReader::readColumn (BtrReader.cpp:31-74) with the
  * nullmap of BitmapWrapper::writeBITMAP (extern/RoaringBitmap.cpp:32-53). Copies the chunk to the
