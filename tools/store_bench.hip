@@ -80,6 +80,29 @@ __global__ void __launch_bounds__(256) fill_flat(u32* __restrict__ dst, u32 v, s
     if (i < quads) { if (NT) __builtin_nontemporal_store(val, p + i); else p[i] = val; }
   }
 }
+// copies: one workgroup per 256 KiB block (as the engine's UNCOMPRESSED root) and one 4 KiB page per workgroup
+template <int UNROLL, bool NT>
+__global__ void __launch_bounds__(256) copy_block(u32* __restrict__ dst, const u32* __restrict__ src) {
+  u32x4* p = reinterpret_cast<u32x4*>(dst + (size_t)blockIdx.x * 65536);
+  const u32x4* q = reinterpret_cast<const u32x4*>(src + (size_t)blockIdx.x * 65536);
+  for (u32 base = 0; base < 16384; base += 256 * UNROLL) {
+    u32x4 v[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; u++) v[u] = q[base + u * 256 + threadIdx.x];
+#pragma unroll
+    for (int u = 0; u < UNROLL; u++) {
+      if (NT) __builtin_nontemporal_store(v[u], p + base + u * 256 + threadIdx.x);
+      else p[base + u * 256 + threadIdx.x] = v[u];
+    }
+  }
+}
+template <bool NT>
+__global__ void __launch_bounds__(256) copy_page(u32* __restrict__ dst, const u32* __restrict__ src) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const u32x4 v = reinterpret_cast<const u32x4*>(src)[i];
+  if (NT) __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(dst) + i);
+  else reinterpret_cast<u32x4*>(dst)[i] = v;
+}
 template <typename F>
 static void timeit(const char* name, F launch, size_t bytes) {
   hipEvent_t a, b; CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
@@ -136,6 +159,13 @@ int main() {
   const u32 flat = (u32)((quads + 1023) / 1024);
   timeit("flat 16 KiB per workgroup nt", [&] { fill_flat<true><<<flat, 256>>>(d, 7, quads); }, n * 4);
   timeit("flat 16 KiB per workgroup plain", [&] { fill_flat<false><<<flat, 256>>>(d, 7, quads); }, n * 4);
+  u32* src; CHECK(hipMalloc(&src, n * 4)); CHECK(hipMemset(src, 1, n * 4));
+  timeit("copy block 256 KiB unroll4 nt (read+write)", [&] { copy_block<4, true><<<blocks, 256>>>(d, src); }, n * 8);
+  timeit("copy block 256 KiB unroll4 plain", [&] { copy_block<4, false><<<blocks, 256>>>(d, src); }, n * 8);
+  timeit("copy block 256 KiB unroll8 nt", [&] { copy_block<8, true><<<blocks, 256>>>(d, src); }, n * 8);
+  timeit("copy 4 KiB page per workgroup nt", [&] { copy_page<true><<<n / 1024, 256>>>(d, src); }, n * 8);
+  timeit("copy 4 KiB page per workgroup plain", [&] { copy_page<false><<<n / 1024, 256>>>(d, src); }, n * 8);
+  timeit("hipMemcpyAsync device to device", [&] { CHECK(hipMemcpyAsync(d, src, n * 4, hipMemcpyDeviceToDevice, 0)); }, n * 8);
   CHECK(hipMemset(d, 0, n * 4));
   timeit("hipMemsetAsync", [&] { CHECK(hipMemsetAsync(d, 1, n * 4, 0)); }, n * 4);
   return 0;
