@@ -1249,7 +1249,9 @@ btr_status btr_gpu_decode(btr_gpu_ctx* ctx, btr_gpu_plan* plan, void* hip_stream
   // need more LDS than the main launch leaves free on any CU) are then dispatched onto an empty GPU
   // instead of queueing for a slot until the main grid has been handed out.
   for (size_t j = 1; j < n; j++) {
-    hipStream_t on = ctx->lane[ctx->next_side++ % kColumnLanes];
+    // lanes 1..3, as for the large launches above: lane 0 was seen to share its hardware queue with the
+    // default stream, and a side launch in the caller's own queue runs before the main launch, not beside it
+    hipStream_t on = ctx->lane[1 + ctx->next_side++ % (kColumnLanes - 1)];
     HIP_TRY(hipStreamWaitEvent(on, plan->fork, 0));
     HIP_TRY(hipEventRecord(plan->go[j], on));
     HIP_TRY(launch(j, on));
