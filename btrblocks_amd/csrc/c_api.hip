@@ -1275,14 +1275,17 @@ btr_status btr_gpu_decode_columns(btr_gpu_ctx* ctx, btr_gpu_plan* const* plans, 
   if (!guard.ok) return fail(BTR_ERR_DEVICE, "hipSetDevice failed");
   hipStream_t stream = (hipStream_t)hip_stream;
   std::lock_guard<std::recursive_mutex> lock(ctx->streams_mutex);
+  // plan i goes to slot i mod 4: slot 0 is the caller's stream itself, slots 1..3 are lanes 1..3 of the
+  // context (lane 0 shares its hardware queue with the default stream, see btr_gpu_decode)
   const uint32_t used = (uint32_t)std::min<size_t>(n, kColumnLanes);
   HIP_TRY(hipEventRecord(ctx->lanes_fork, stream));
-  for (uint32_t k = 0; k < used; k++) HIP_TRY(hipStreamWaitEvent(ctx->lane[k], ctx->lanes_fork, 0));
+  for (uint32_t k = 1; k < used; k++) HIP_TRY(hipStreamWaitEvent(ctx->lane[k], ctx->lanes_fork, 0));
   for (size_t i = 0; i < n; i++) {
-    const btr_status st = btr_gpu_decode(ctx, plans[i], ctx->lane[i % kColumnLanes]);
+    const uint32_t slot = (uint32_t)(i % kColumnLanes);
+    const btr_status st = btr_gpu_decode(ctx, plans[i], slot ? ctx->lane[slot] : stream);
     if (st != BTR_OK) return st;
   }
-  for (uint32_t k = 0; k < used; k++) {
+  for (uint32_t k = 1; k < used; k++) {
     HIP_TRY(hipEventRecord(ctx->lane_done[k], ctx->lane[k]));
     HIP_TRY(hipStreamWaitEvent(stream, ctx->lane_done[k], 0));
   }
