@@ -271,6 +271,8 @@ def parse_args():
     ap.add_argument("--no-verify", action="store_true", help="skip the oracle check of a sample of blocks after the timed region")
     ap.add_argument("--verify-stride", type=int, default=257, help="check every N-th chunk (and the last one)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
+    ap.add_argument("--init-dist", action="store_true",
+                    help="N = 1 rehearsal: initialise a one-rank process group (and use its barrier) as a rank of an N > 1 run does")
     ap.add_argument("--one-device", action="store_true",
                     help="rehearsal on a one-GPU box: every rank uses cuda:0 (needs --backend gloo)")
     return ap.parse_args()
@@ -325,8 +327,12 @@ def run_rank(args):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.one_device:
         local_rank = 0
-    if world > 1:
+    if world > 1 or args.init_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:  # rehearsal: a one-rank group, so that the process holds RCCL's streams like a rank of an N > 1 run
+            os.environ.setdefault("MASTER_PORT", "29533")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
@@ -365,7 +371,7 @@ def run_rank(args):
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if world > 1 or args.init_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -634,7 +640,7 @@ def run_rank(args):
         if not args.no_cpu_baseline:  # rank 0's host cores, on rank 0's own chunks
             line["cpu_baseline"] = cpu_baseline(cols, min(args.cpu_sample_chunks, max(8, 3072 // len(cols))))
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if world > 1 or args.init_dist:
         dist.barrier()
         dist.destroy_process_group()
 
