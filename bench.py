@@ -262,6 +262,7 @@ def parse_args():
     ap.add_argument("--beside-leg", action="store_true",
                     help="N = 1: after the timed region, time the same step with the columns beside each other as well "
                          "(columns_beside_each_other; its launches overlap, so leave it out of profiled runs)")
+    ap.add_argument("--no-copy-ceiling", action="store_true", help="skip the device-to-device copy rate in the roofline object")
     ap.add_argument("--no-plan-leg", action="store_true",
                     help="N = 1: skip the secondary leg that decodes the step through one plan over all columns")
     ap.add_argument("--serial", action="store_true", help="N > 1: one column launch after the other, as at N = 1")
@@ -512,6 +513,25 @@ def run_rank(args):
     achieved = dom_alg / (mean_ms[dom] / 1e3) / 1e9          # GB/s of the dominant kernel's launches
     achieved_all = alg_bytes / (mean_ms.sum() / 1e3) / 1e9   # GB/s over all launches of a step
 
+    copy_ceiling = None
+    if rank == 0 and not args.no_copy_ceiling:
+        # what the box's own device-to-device copy reaches (read + written bytes): context for the fraction of
+        # the 8 TB/s spec peak that `roofline.frac` is quoted against
+        try:
+            a = torch.empty(1 << 28, dtype=torch.int32, device=dev)
+            b = torch.empty_like(a)
+            for _ in range(3):
+                b.copy_(a)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                b.copy_(a)
+            e1.record()
+            torch.cuda.synchronize()
+            copy_ceiling = round(10 * 2 * a.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
+            del a, b
+        except Exception:
+            copy_ceiling = None
     if rank == 0:
         # HBM bytes per launch of the dominant kernel: not collected in this run (counters need rocprofv3
         # passes of their own, profiles/collect.sh) but read from the tracked summary of those passes. The
@@ -586,6 +606,8 @@ def run_rank(args):
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": traffic,
                 "traffic_source": traffic_source,
+                "peak_source": "MI355X HBM3E specification (8 TB/s); frac = achieved / peak",
+                "device_copy_GBps": copy_ceiling,  # torch device-to-device copy of 1 GiB on this GPU, read + written bytes
                 "kernel": ",".join(per_column[cols[dom]["name"]]["kernels"]),
                 "column": cols[dom]["name"],
                 "alg_bytes_per_launch": int(dom_alg),

@@ -11,7 +11,7 @@ mkdir -p $out
 export TMPDIR=/tmp
 timeout -k 10 400 python3 -u bench.py --relation --no-cpu-baseline --no-pipeline > $out/${tag}_config4_bench.json 2> $out/${tag}_config4.err || { tail -5 $out/${tag}_config4.err; exit 1; }
 timeout -k 10 400 python3 -u bench.py --relation --serial --no-cpu-baseline --no-pipeline --no-verify > $out/${tag}_config4_serial.json 2>> $out/${tag}_config4.err || { tail -5 $out/${tag}_config4.err; exit 1; }
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_config4_prof -o ${tag}_config4 -- python3 bench.py --relation --serial --steps 10 --no-cpu-baseline --no-pipeline --no-verify > $out/${tag}_config4_prof.log 2>&1 || { tail -5 $out/${tag}_config4_prof.log; exit 1; }
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_config4_prof -o ${tag}_config4 -- python3 bench.py --relation --serial --steps 10 --no-cpu-baseline --no-pipeline --no-verify --no-copy-ceiling > $out/${tag}_config4_prof.log 2>&1 || { tail -5 $out/${tag}_config4_prof.log; exit 1; }
 timeout -k 10 300 python3 -u bench.py --relation --rows 33554432 --steps 40 --no-pipeline > $out/${tag}_eighth_plan.json 2> $out/${tag}_eighth.err || { tail -5 $out/${tag}_eighth.err; exit 1; }
 timeout -k 10 300 python3 -u bench.py --relation --rows 33554432 --steps 40 --serial --no-cpu-baseline --no-pipeline > $out/${tag}_eighth_serial.json 2>> $out/${tag}_eighth.err || { tail -5 $out/${tag}_eighth.err; exit 1; }
 timeout -k 10 300 python3 -u bench.py --relation --rows 33554432 --steps 40 --concurrent --no-cpu-baseline --no-pipeline > $out/${tag}_eighth_concurrent.json 2>> $out/${tag}_eighth.err || { tail -5 $out/${tag}_eighth.err; exit 1; }

@@ -9,6 +9,6 @@ out=gpurun_out
 mkdir -p $out
 export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout -s KILL 400 rocprofv3 --pmc $c --output-format csv -d $out/${tag}_rel_$c -o ${tag} -- python3 bench.py --relation --serial --steps 2 --warmup 1 --no-cpu-baseline --no-pipeline --no-verify > $out/${tag}_rel_$c.log 2>&1 || { tail -5 $out/${tag}_rel_$c.log; exit 1; }
+  timeout -s KILL 400 rocprofv3 --pmc $c --output-format csv -d $out/${tag}_rel_$c -o ${tag} -- python3 bench.py --relation --serial --steps 2 --warmup 1 --no-cpu-baseline --no-pipeline --no-verify --no-copy-ceiling > $out/${tag}_rel_$c.log 2>&1 || { tail -5 $out/${tag}_rel_$c.log; exit 1; }
 done
 find $out/${tag}_rel_FETCH_SIZE $out/${tag}_rel_WRITE_SIZE -name "*counter_collection.csv"

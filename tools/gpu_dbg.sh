@@ -4,7 +4,7 @@
 export BTR_LIB_PATH=$PWD/btrblocks_amd/libbtrblocks_amd_dbg.so
 mkdir -p gpurun_out
 for f in $1; do
-BTR_DEBUG_FLAGS=$f timeout -k 10 200 python -u bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-pipeline --no-verify --no-plan-leg --columns $2 > gpurun_out/dbg_$f.log 2>&1
+BTR_DEBUG_FLAGS=$f timeout -k 10 200 python -u bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-pipeline --no-verify --no-plan-leg --no-copy-ceiling --columns $2 > gpurun_out/dbg_$f.log 2>&1
 python - <<PY
 import json
 l=[x for x in open("gpurun_out/dbg_$f.log") if x.startswith("{")]

@@ -7,7 +7,7 @@ tag=$1; cols=$2; shift 2
 out=gpurun_out
 mkdir -p $out
 export TMPDIR=/tmp
-timeout -s KILL 120 rocprofv3 --pmc "$@" --output-format csv -d $out/${tag}_pmc -o ${tag} -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-pipeline --no-verify --no-plan-leg --columns $cols > $out/${tag}_pmc.log 2>&1 || { tail -5 $out/${tag}_pmc.log; exit 1; }
+timeout -s KILL 120 rocprofv3 --pmc "$@" --output-format csv -d $out/${tag}_pmc -o ${tag} -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-pipeline --no-verify --no-plan-leg --no-copy-ceiling --columns $cols > $out/${tag}_pmc.log 2>&1 || { tail -5 $out/${tag}_pmc.log; exit 1; }
 python3 - <<PY
 import csv, glob, collections
 f = glob.glob("$out/${tag}_pmc/**/*counter_collection.csv", recursive=True)[0]

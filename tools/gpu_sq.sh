@@ -6,7 +6,7 @@ tag=$1; cols=$2
 out=gpurun_out
 mkdir -p $out
 export TMPDIR=/tmp
-timeout -s KILL 120 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_ACTIVE_INST_LDS SQ_BUSY_CYCLES --output-format csv -d $out/${tag}_sq -o ${tag} -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-pipeline --no-verify --no-plan-leg --columns $cols > $out/${tag}_sq.log 2>&1 || { tail -5 $out/${tag}_sq.log; exit 1; }
+timeout -s KILL 120 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_ACTIVE_INST_LDS SQ_BUSY_CYCLES --output-format csv -d $out/${tag}_sq -o ${tag} -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-pipeline --no-verify --no-plan-leg --no-copy-ceiling --columns $cols > $out/${tag}_sq.log 2>&1 || { tail -5 $out/${tag}_sq.log; exit 1; }
 python3 - <<PY
 import csv, glob, collections
 f = glob.glob("$out/${tag}_sq/**/*counter_collection.csv", recursive=True)[0]
