@@ -332,7 +332,7 @@ uint32_t debug_flags_from_env() {
 struct Layout {
   std::vector<uint8_t> blob;
   std::vector<LaunchEntry> order;
-  std::vector<LaunchGroup> launches;  // the one with the most decoded bytes first
+  std::vector<LaunchGroup> launches;  // the one with the most estimated work (LaunchGroup::weight) first
   uint64_t scratch = 0;
 };
 
@@ -1224,7 +1224,8 @@ btr_status btr_gpu_decode(btr_gpu_ctx* ctx, btr_gpu_plan* plan, void* hip_stream
   std::lock_guard<std::recursive_mutex> lock(ctx->streams_mutex);
   HIP_TRY(hipEventRecord(plan->fork, stream));
   if (plan->balanced) {
-    // several large launches, all of them on lanes of the context; one join per lane, behind its last launch
+    // several large launches on the caller's stream and lanes of the context (btr_gpu_plan::lane); one join per
+    // lane, behind its last launch
     bool forked[kColumnLanes + 1] = {};
     size_t last_on[kColumnLanes + 1];
     for (size_t j = 0; j < n; j++) last_on[plan->lane[j]] = j;
