@@ -46,12 +46,9 @@ int main(int argc, char** argv) {
       Chunk decompressed = compressor.decompress(output);
       check = check && (input == decompressed);
     }
-    std::cout << "Stats:" << std::endl
-              << "- input size " << raw << std::endl
-              << "- output size " << compressed << std::endl
-              << "- compression ratio " << (compressed ? (double)raw / compressed : 0) << std::endl
-              << "- blocks " << ranges.size() << std::endl;
-    std::cout << (check ? "decompressed data matches original data" : "decompressed data does not match original data")
+    std::cout << "relation of " << ranges.size() << " blocks: " << raw << " raw bytes -> " << compressed << " compressed bytes ("
+              << (compressed ? (double)raw / compressed : 0) << " x)" << std::endl;
+    std::cout << (check ? "block round trip: every block decodes to its input" : "block round trip: MISMATCH")
               << std::endl;
 
     // The column-part path the reference's decompression-speed tool times
@@ -79,7 +76,7 @@ int main(int argc, char** argv) {
         reader.releaseBitmap(i);
         row += n;
       }
-      std::cout << (part_ok ? "column part reader matches original data" : "column part reader does not match original data")
+      std::cout << (part_ok ? "part reader round trip: every chunk decodes to its input" : "part reader round trip: MISMATCH")
                 << std::endl;
       check = check && part_ok;
     }

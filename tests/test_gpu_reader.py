@@ -169,8 +169,8 @@ def test_cpp_interface_round_trip(spec):
     exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "compression")
     r = subprocess.run([exe, "640000", spec], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert "decompressed data matches original data" in r.stdout
-    assert "column part reader matches original data" in r.stdout
+    assert "block round trip: every block decodes to its input" in r.stdout
+    assert "part reader round trip: every chunk decodes to its input" in r.stdout
 
 
 @pytest.mark.gpu
